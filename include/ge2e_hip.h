@@ -1,0 +1,103 @@
+/*
+ * ge2e_hip.h -- C ABI of libge2e_hip.so: the GE2E speaker-verification loss
+ * (forward + full gradient) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * This is the drop-in boundary for the hot path of
+ * gkv856/speaker_embedding_GE2E_loss:
+ *     embedding_model_GE2E/s3_loss_function_GE2E.py:19-30   GE2ELoss.forward
+ *     embedding_model_GE2E/s3_loss_function_GE2E.py:34-127  get_centroids,
+ *         get_cos_sim, get_utterance_centroids, calc_loss
+ *     embedding_model_GE2E/s4_train_embed_model.py:200      loss.backward()
+ * The reference has no native layer; these entry points are what a ctypes /
+ * torch binding for that path binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless it says host;
+ *   - all tensors are dense, row-major, float32;  E is [B][N][M][D]
+ *     (B independent (speakers x utterances) batches, N speakers, M utterances
+ *     per speaker, D embedding size); B = 1 is the reference's single batch;
+ *   - the caller owns every buffer including the workspace; the library
+ *     allocates nothing, keeps no state and never synchronises: calls only
+ *     enqueue work on `stream` (a hipStream_t passed as void*, NULL = default);
+ *   - w and b (s3:16-17) are read from device memory, no host sync;
+ *   - return value: 0 = ok, < 0 = argument error (GE2E_ERR_*), > 0 = hipError_t
+ *     of a failed launch.  Nothing is thrown across the boundary.
+ */
+#ifndef GE2E_HIP_H
+#define GE2E_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GE2E_ABI_VERSION 1
+
+/* loss variants: eq. (6) softmax is the reference's (s3:115-127); eq. (7)
+ * contrast is defined from arXiv:1710.10467 (absent from the reference). */
+#define GE2E_VARIANT_SOFTMAX 0
+#define GE2E_VARIANT_CONTRAST 1
+
+/* kernel selection */
+#define GE2E_IMPL_AUTO 0        /* fastest implementation valid for the shape   */
+#define GE2E_IMPL_GENERIC 1     /* one workgroup per batch, fp32 VALU, any shape */
+#define GE2E_IMPL_FUSED_F32 2   /* one workgroup per batch, LDS-resident centroids,
+                                   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
+#define GE2E_IMPL_FUSED_SPLIT 3 /* as FUSED_F32 with fp16 hi+lo split operands on
+                                   v_mfma_f32_32x32x16_f16, fp32 accumulate      */
+#define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
+
+#define GE2E_OK 0
+#define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */
+#define GE2E_ERR_SHAPE (-2)     /* B,N,D < 1 or M < 2 (M = 1 divides by zero in
+                                   the reference, s3:110-111)                    */
+#define GE2E_ERR_WORKSPACE (-3) /* workspace NULL/too small/misaligned (256 B)   */
+#define GE2E_ERR_VARIANT (-4)
+#define GE2E_ERR_IMPL (-5)      /* requested impl cannot run this shape          */
+#define GE2E_ERR_ALIGN (-6)     /* E / dE not 16-byte aligned                    */
+
+int ge2e_abi_version(void);
+const char* ge2e_strerror(int code);
+
+/* Which implementation GE2E_IMPL_AUTO resolves to for a shape (or `impl`
+ * itself if it is valid for the shape, GE2E_ERR_IMPL if not). */
+int ge2e_resolve_impl(int B, int N, int M, int D, int variant, int impl);
+
+/* Bytes of scratch ge2e_loss_fwd_bwd / ge2e_cos_sim need for this shape. */
+size_t ge2e_workspace_bytes(int B, int N, int M, int D, int variant, int impl);
+
+/*
+ * GE2ELoss.forward + its autograd backward in one call (s3:19-30 + s4:200).
+ *   loss          [B]        sum over the (N,M) per-utterance losses (s3:126)
+ *   per_emb_loss  [B][N][M]  calc_loss()'s second return value, or NULL
+ *   dE            [B][N][M][D] dLoss/dE, or NULL for forward only
+ *   dw, db        [B]        dLoss/dw, dLoss/db (NULL allowed when dE is NULL)
+ * eps_cos = F.cosine_similarity's eps (1e-8); eps = hp.general.small_err (1e-6).
+ */
+int ge2e_loss_fwd_bwd(const float* E, int B, int N, int M, int D,
+                      const float* w, const float* b, float eps_cos, float eps,
+                      int variant, int impl,
+                      float* loss, float* per_emb_loss,
+                      float* dE, float* dw, float* db,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* GE2ELoss.get_cos_sim (s3:42-80): cos [B][N][M][N], leave-one-out centroid on
+ * the own-speaker column, eps added to every entry.  Forward-only consumer:
+ * s5_eval_model.py:42-44. */
+int ge2e_cos_sim(const float* E, int B, int N, int M, int D,
+                 float eps_cos, float eps, float* cos,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* GE2ELoss.calc_loss (s3:115-127) on a caller-made similarity matrix
+ * sim [B][N][M][N]:  loss [B], per_emb_loss [B][N][M] (or NULL).  Forward only. */
+int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant,
+                   float* loss, float* per_emb_loss, void* stream);
+
+/* GE2ELoss.get_centroids (s3:34-38): cent [B][N][D] = mean over M. */
+int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GE2E_HIP_H */

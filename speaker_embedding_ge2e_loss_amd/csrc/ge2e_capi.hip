@@ -1,0 +1,117 @@
+// extern "C" boundary of libge2e_hip.so (include/ge2e_hip.h): argument checks,
+// implementation choice, workspace sizing, launches.  No allocation, no sync, no state.
+#include "../../include/ge2e_hip.h"
+
+#include <math.h>
+
+#include "ge2e_common.hpp"
+#include "ge2e_generic.hpp"
+
+using namespace ge2e;
+
+namespace {
+
+bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
+
+int resolve(int B, int N, int M, int D, int variant, int impl) {
+    (void)B; (void)N; (void)M; (void)D; (void)variant;
+    switch (impl) {
+        case GE2E_IMPL_AUTO: return GE2E_IMPL_GENERIC;
+        case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;
+        default: return GE2E_ERR_IMPL;
+    }
+}
+
+size_t ws_bytes(int B, int N, int M, int D, int impl) {
+    switch (impl) {
+        case GE2E_IMPL_GENERIC: return generic_workspace_bytes(B, N, M, D);
+        default: return 0;
+    }
+}
+
+int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!shape_ok(p.B, p.N, p.M, p.D)) return GE2E_ERR_SHAPE;
+    if (p.variant != GE2E_VARIANT_SOFTMAX && p.variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    const int chosen = resolve(p.B, p.N, p.M, p.D, p.variant, impl);
+    if (chosen < 0) return chosen;
+    const size_t need = ws_bytes(p.B, p.N, p.M, p.D, chosen);
+    if (need > 0 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))) return GE2E_ERR_WORKSPACE;
+    if (((uintptr_t)p.E & 15) || ((uintptr_t)p.dE & 15)) return GE2E_ERR_ALIGN;
+    p.ws = (float*)workspace;
+    p.log_eps = p.eps > 0.f ? logf(p.eps) : -INFINITY;
+    hipError_t err = hipSuccess;
+    switch (chosen) {
+        case GE2E_IMPL_GENERIC: err = launch_generic(p, (hipStream_t)stream); break;
+        default: return GE2E_ERR_IMPL;
+    }
+    return (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ge2e_abi_version(void) { return GE2E_ABI_VERSION; }
+
+const char* ge2e_strerror(int code) {
+    switch (code) {
+        case GE2E_OK: return "ok";
+        case GE2E_ERR_NULL: return "required pointer is NULL";
+        case GE2E_ERR_SHAPE: return "bad shape: need B,N,D >= 1 and M >= 2";
+        case GE2E_ERR_WORKSPACE: return "workspace missing, too small or not 256-byte aligned";
+        case GE2E_ERR_VARIANT: return "unknown loss variant";
+        case GE2E_ERR_IMPL: return "requested implementation cannot run this shape";
+        case GE2E_ERR_ALIGN: return "E / dE must be 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int ge2e_resolve_impl(int B, int N, int M, int D, int variant, int impl) {
+    if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
+    return resolve(B, N, M, D, variant, impl);
+}
+
+size_t ge2e_workspace_bytes(int B, int N, int M, int D, int variant, int impl) {
+    if (!shape_ok(B, N, M, D)) return 0;
+    const int chosen = resolve(B, N, M, D, variant, impl);
+    return chosen < 0 ? 0 : ws_bytes(B, N, M, D, chosen);
+}
+
+int ge2e_loss_fwd_bwd(const float* E, int B, int N, int M, int D, const float* w, const float* b,
+                      float eps_cos, float eps, int variant, int impl, float* loss,
+                      float* per_emb_loss, float* dE, float* dw, float* db, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!E || !w || !b || !loss) return GE2E_ERR_NULL;
+    if (dE && (!dw || !db)) return GE2E_ERR_NULL;
+    Problem p{};
+    p.E = E; p.w = w; p.b = b; p.loss = loss; p.per = per_emb_loss;
+    p.dE = dE; p.dw = dw; p.db = db; p.cos_out = nullptr;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = variant; p.eps_cos = eps_cos; p.eps = eps;
+    return run(p, impl, workspace, workspace_bytes, stream);
+}
+
+// Forward-only similarity matrix; w and b are not applied (s5:44 applies its own).
+int ge2e_cos_sim(const float* E, int B, int N, int M, int D, float eps_cos, float eps, float* cos,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!E || !cos) return GE2E_ERR_NULL;
+    Problem p{};
+    p.E = E; p.w = nullptr; p.b = nullptr; p.w_imm = 1.0f; p.b_imm = 0.0f; p.cos_out = cos;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = GE2E_VARIANT_SOFTMAX; p.eps_cos = eps_cos; p.eps = eps;
+    return run(p, GE2E_IMPL_GENERIC, workspace, workspace_bytes, stream);
+}
+
+int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
+                   float* per_emb_loss, void* stream) {
+    if (!sim || !loss) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1) return GE2E_ERR_SHAPE;
+    if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    return (int)launch_calc_loss(sim, B, N, M, eps, variant, loss, per_emb_loss, (hipStream_t)stream);
+}
+
+int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream) {
+    if (!E || !cent) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1 || D < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_centroids(E, B, N, M, D, cent, (hipStream_t)stream);
+}
+
+}  // extern "C"
