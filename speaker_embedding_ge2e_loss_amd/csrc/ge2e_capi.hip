@@ -6,6 +6,7 @@
 
 #include "ge2e_common.hpp"
 #include "ge2e_generic.hpp"
+#include "ge2e_fused.hpp"
 
 using namespace ge2e;
 
@@ -14,10 +15,12 @@ namespace {
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
-    (void)B; (void)N; (void)M; (void)D; (void)variant;
+    (void)B; (void)variant;
     switch (impl) {
-        case GE2E_IMPL_AUTO: return GE2E_IMPL_GENERIC;
+        case GE2E_IMPL_AUTO:
+            return fused_f32_supports(N, M, D) ? GE2E_IMPL_FUSED_F32 : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;
+        case GE2E_IMPL_FUSED_F32: return fused_f32_supports(N, M, D) ? GE2E_IMPL_FUSED_F32 : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -25,6 +28,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
 size_t ws_bytes(int B, int N, int M, int D, int impl) {
     switch (impl) {
         case GE2E_IMPL_GENERIC: return generic_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_FUSED_F32: return fused_f32_workspace_bytes(B, N, M, D);
         default: return 0;
     }
 }
@@ -42,6 +46,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
     hipError_t err = hipSuccess;
     switch (chosen) {
         case GE2E_IMPL_GENERIC: err = launch_generic(p, (hipStream_t)stream); break;
+        case GE2E_IMPL_FUSED_F32: err = launch_fused_f32(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;

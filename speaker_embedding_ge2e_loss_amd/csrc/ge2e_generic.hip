@@ -107,15 +107,18 @@ __global__ __launch_bounds__(256) void ge2e_generic_kernel(Problem p, size_t ws_
             float per, coef = 0.f, ad = 0.f;
             if (!contrast) {
                 mx = fmaxf(wave_max(mx), log_eps);
-                float z = 0.f;
-                for (int k = lane; k < N; k += kWave) z += expf(w * (Arow[k] + eps) + bias - mx);
-                z = wave_sum(z) + expf(log_eps - mx);
+                // z_off = everything except the own-speaker term: 1 - p_jj = z_off / z has no
+                // cancellation when the softmax is peaked on the diagonal (trained embeddings)
+                float zoff = 0.f;
+                for (int k = lane; k < N; k += kWave)
+                    if (k != j) zoff += expf(w * (Arow[k] + eps) + bias - mx);
+                zoff = wave_sum(zoff) + expf(log_eps - mx);
+                const float z = zoff + expf(sjj - mx);
                 per = (mx - sjj) + logf(z);
                 const float rz = 1.0f / z;
                 for (int k = lane; k < N; k += kWave) {
                     const float c0 = Arow[k];
-                    float g = expf(w * (c0 + eps) + bias - mx) * rz;
-                    if (k == j) g -= 1.0f;
+                    const float g = (k == j) ? -zoff * rz : expf(w * (c0 + eps) + bias - mx) * rz;
                     dw_acc += g * (c0 + eps);
                     db_acc += g;
                     const float a = w * g;

@@ -15,10 +15,10 @@ from oracle import ge2e_oracle as orc
 pytestmark = pytest.mark.gpu
 
 TOL = {  # impl -> (loss rtol, dE rel-fro / relative max-abs, dw rtol, cos atol)
-    "generic": (5e-6, 5e-6, 2e-5, 2e-6),
-    "fused_f32": (5e-6, 5e-6, 2e-5, 2e-6),
+    "generic": (5e-6, 1e-5, 2e-5, 2e-6),
+    "fused_f32": (5e-6, 1e-5, 2e-5, 2e-6),
     "fused_split": (2e-5, 2e-5, 5e-5, 5e-6),
-    "tiled": (5e-6, 5e-6, 2e-5, 2e-6),
+    "tiled": (5e-6, 1e-5, 2e-5, 2e-6),
     "auto": (1e-4, 1e-4, 1e-4, 1e-5),
 }
 
