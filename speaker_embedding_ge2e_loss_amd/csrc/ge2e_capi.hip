@@ -12,6 +12,10 @@ using namespace ge2e;
 
 namespace {
 
+#ifdef GE2E_PROFILE
+unsigned long long* g_prof = nullptr;  // diagnostic build only
+#endif
+
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
@@ -42,6 +46,9 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
     if (need > 0 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))) return GE2E_ERR_WORKSPACE;
     if (((uintptr_t)p.E & 15) || ((uintptr_t)p.dE & 15)) return GE2E_ERR_ALIGN;
     p.ws = (float*)workspace;
+#ifdef GE2E_PROFILE
+    p.prof = g_prof;
+#endif
     p.log_eps = p.eps > 0.f ? logf(p.eps) : -INFINITY;
     hipError_t err = hipSuccess;
     switch (chosen) {
@@ -55,6 +62,11 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
 }  // namespace
 
 extern "C" {
+
+#ifdef GE2E_PROFILE
+// diagnostic build only (tools/profile_phases.py): where the kernels add their phase stamps
+void ge2e_debug_set_prof(void* device_u64_buffer) { g_prof = (unsigned long long*)device_u64_buffer; }
+#endif
 
 int ge2e_abi_version(void) { return GE2E_ABI_VERSION; }
 

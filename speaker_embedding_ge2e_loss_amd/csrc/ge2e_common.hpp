@@ -26,25 +26,104 @@ struct Problem {
     float eps_cos;    // cosine_similarity eps (1e-8)
     float eps;        // hp.general.small_err (1e-6)
     float log_eps;    // logf(eps), -inf when eps == 0
+    unsigned long long* prof;  // diagnostic builds (-DGE2E_PROFILE) only: per-phase cycle sums
 };
 
+// In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with
+// -DGE2E_PROFILE (tools/profile_phases.py builds that variant); the shipped library has none.
+#ifdef GE2E_PROFILE
+#define GE2E_PROF_DECL(n)                                              \
+    unsigned long long prof_acc[n];                                    \
+    for (int prof_i = 0; prof_i < n; ++prof_i) prof_acc[prof_i] = 0;   \
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#define GE2E_PROF(i)                                                   \
+    do {                                                               \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        unsigned long long prof_now = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+        prof_acc[i] += prof_now - prof_last;                           \
+        prof_last = prof_now;                                          \
+        __builtin_amdgcn_sched_barrier(0);                             \
+    } while (0)
+#define GE2E_PROF_FLUSH(n)                                             \
+    if (threadIdx.x == 0 && p.prof)                                    \
+        for (int prof_i = 0; prof_i < n; ++prof_i) atomicAdd(p.prof + prof_i, prof_acc[prof_i]);
+#else
+#define GE2E_PROF_DECL(n)
+#define GE2E_PROF(i)
+#define GE2E_PROF_FLUSH(n)
+#endif
+
+// ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps), no LDS round trips ----
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-crossbar op with ~100-cycle dependent
+// latency per step); these stay in the vector pipe.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each group of 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i inside each row of 16
+
+// lanes l and l^16 (SWAP16) / l and l^32 (SWAP32): both values of the pair, in either order
+#define GE2E_SWAP16(u) __builtin_amdgcn_permlane16_swap((u), (u), false, false)
+#define GE2E_SWAP32(u) __builtin_amdgcn_permlane32_swap((u), (u), false, false)
+
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); return v; }
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); return v;
+}
+// sum / max over each aligned group of 16 lanes, result in all 16
+__device__ __forceinline__ float row16_sum(float v) {
+    v = quad_sum(v); v += dpp_f<DPP_HALF_MIRROR>(v); v += dpp_f<DPP_MIRROR>(v); return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = quad_max(v); v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_MIRROR>(v)); return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v = row16_sum(v);
+    auto a = GE2E_SWAP16(__float_as_uint(v));
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = GE2E_SWAP32(__float_as_uint(v));
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
+    v = row16_max(v);
+    auto a = GE2E_SWAP16(__float_as_uint(v));
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = GE2E_SWAP32(__float_as_uint(v));
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // (value, index) arg-max; ties resolve to the lowest index (torch.max picks the first).
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void quad_argmax(float& v, int& i) {
+    argmax_merge(v, i, dpp_f<DPP_XOR1>(v), dpp_i<DPP_XOR1>(i));
+    argmax_merge(v, i, dpp_f<DPP_XOR2>(v), dpp_i<DPP_XOR2>(i));
+}
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o, kWave);
-        int oi = __shfl_xor(i, o, kWave);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    quad_argmax(v, i);
+    argmax_merge(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));
+    argmax_merge(v, i, dpp_f<DPP_MIRROR>(v), dpp_i<DPP_MIRROR>(i));
+    {
+        auto a = GE2E_SWAP16(__float_as_uint(v));
+        auto b = GE2E_SWAP16((unsigned)i);
+        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
+        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
+        v = v0; i = i0;
+    }
+    {
+        auto a = GE2E_SWAP32(__float_as_uint(v));
+        auto b = GE2E_SWAP32((unsigned)i);
+        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
+        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
+        v = v0; i = i0;
     }
 }
 

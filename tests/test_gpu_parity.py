@@ -48,7 +48,11 @@ def run_hip(GF, E, w, b, variant="softmax", impl="auto", eps=1e-6):
     e = torch.as_tensor(E, device=dev)
     wt = torch.tensor(float(w), device=dev)
     bt = torch.tensor(float(b), device=dev)
-    o = GF.loss_fwd_bwd(e, wt, bt, variant=variant, impl=impl, eps=eps, need_per=True)
+    # poison every output first: a kernel that skips rows must not pass on stale allocator memory
+    shp = tuple(e.shape) if e.dim() == 4 else (1,) + tuple(e.shape)
+    nan = lambda *s: torch.full(s, float("nan"), device=dev)  # noqa: E731
+    out = GF.LossOutputs(loss=nan(shp[0]), per=nan(*shp[:3]), dE=nan(*shp), dw=nan(shp[0]), db=nan(shp[0]))
+    o = GF.loss_fwd_bwd(e, wt, bt, variant=variant, impl=impl, eps=eps, out=out)
     torch.cuda.synchronize()
     squeeze = (lambda t: t[0]) if e.dim() == 3 else (lambda t: t)
     return {k: squeeze(getattr(o, k)).cpu().numpy() for k in ("loss", "per", "dE", "dw", "db")}

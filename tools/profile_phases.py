@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a fused-kernel workgroup spend its cycles?
+
+Builds a SEPARATE library (libge2e_hip_prof.so, -DGE2E_PROFILE) whose kernels stamp
+s_memtime at every phase boundary (wave 0's view, after the workgroup barrier), runs one
+launch and prints cycles per batch per phase.  The stamps serialise issue at the phase
+boundaries, so read the SHARES, not the total.  The shipped library contains no stamps.
+
+    python tools/profile_phases.py [--impl fused_f32] [--config cfg2] [--batches 1024]
+"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speaker_embedding_ge2e_loss_amd import _lib, build  # noqa: E402
+import bench  # noqa: E402
+
+PHASES = {
+    "fused_f32": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
+                  "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
+    "fused_split": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
+                    "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--impl", default="fused_f32")
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--batches", type=int, default=1024)
+    args = ap.parse_args()
+    lib_path = os.path.join(build.PKG_DIR, "libge2e_hip_prof.so")
+    cmd = [build._hipcc(), "-O3", "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-shared",
+           "-DGE2E_PROFILE", f"-I{build.INCLUDE}", "-o", lib_path] + build.sources()
+    subprocess.run(cmd, check=True)
+    lib = C.CDLL(lib_path)
+    for name, (res, argt) in _lib.PROTOTYPES.items():
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = argt
+    lib.ge2e_debug_set_prof.argtypes = [C.c_void_p]
+    lib.ge2e_debug_set_prof.restype = None
+
+    cfg = bench.CONFIGS[args.config]
+    N, M, D, variant = cfg["N"], cfg["M"], cfg["D"], cfg["variant"]
+    B = args.batches
+    dev = torch.device("cuda:0")
+    E = bench.synth(B, N, M, D, 1234, dev)
+    w = torch.tensor(10.0, device=dev)
+    b = torch.tensor(-5.0, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    loss, dw, db, dE = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32), torch.empty_like(E)
+    v, im = _lib.VARIANTS[variant], _lib.IMPLS[args.impl]
+    ws = torch.empty(lib.ge2e_workspace_bytes(B, N, M, D, v, im) + 256, dtype=torch.uint8, device=dev)
+    prof = torch.zeros(16, dtype=torch.int64, device=dev)
+    lib.ge2e_debug_set_prof(prof.data_ptr())
+
+    def run():
+        code = lib.ge2e_loss_fwd_bwd(E.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), 1e-8, 1e-6, v, im,
+                                     loss.data_ptr(), None, dE.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert code == 0, code
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    prof.zero_()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    run()
+    t1.record()
+    torch.cuda.synchronize()
+    cyc = prof.cpu().numpy().astype(float) / B
+    tot = cyc.sum()
+    names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])
+    print(f"{args.impl} {args.config} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
+          f"{tot:.0f} cycles per batch per workgroup")
+    for i, n in enumerate(names):
+        if cyc[i] > 0:
+            print(f"  {n:18s} {cyc[i]:10.0f} cyc  {100 * cyc[i] / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
