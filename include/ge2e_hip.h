@@ -97,6 +97,14 @@ int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant
 /* GE2ELoss.get_centroids (s3:34-38): cent [B][N][D] = mean over M. */
 int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream);
 
+/* ---- diagnostics (tests only): device building blocks on caller data ------------------- */
+/* A,Bm [64][256], G [64][64] (|x| <= 1) -> X [64][64] = A.Bm^T, GE [64][256] = G.A,
+ * GC [64][256] = G^T.Bm through the split-fp16 MFMA tile contractions. */
+int ge2e_selftest_split_gemm(const float* A, const float* Bm, const float* G,
+                             float* X, float* GE, float* GC, void* stream);
+/* x [64] -> out [384]: wave_sum, wave_max, row16_sum, quad_sum, wave_argmax idx, quad_argmax idx. */
+int ge2e_selftest_wave_ops(const float* x, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include "ge2e_common.hpp"
 #include "ge2e_generic.hpp"
 #include "ge2e_fused.hpp"
+#include "ge2e_selftest.hpp"
 
 using namespace ge2e;
 
@@ -25,6 +26,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
             return fused_f32_supports(N, M, D) ? GE2E_IMPL_FUSED_F32 : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;
         case GE2E_IMPL_FUSED_F32: return fused_f32_supports(N, M, D) ? GE2E_IMPL_FUSED_F32 : GE2E_ERR_IMPL;
+        case GE2E_IMPL_FUSED_SPLIT: return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -33,6 +35,7 @@ size_t ws_bytes(int B, int N, int M, int D, int impl) {
     switch (impl) {
         case GE2E_IMPL_GENERIC: return generic_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_FUSED_F32: return fused_f32_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
         default: return 0;
     }
 }
@@ -54,6 +57,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
     switch (chosen) {
         case GE2E_IMPL_GENERIC: err = launch_generic(p, (hipStream_t)stream); break;
         case GE2E_IMPL_FUSED_F32: err = launch_fused_f32(p, (hipStream_t)stream); break;
+        case GE2E_IMPL_FUSED_SPLIT: err = launch_fused_split(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;
@@ -129,6 +133,17 @@ int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void
     if (!E || !cent) return GE2E_ERR_NULL;
     if (B < 1 || N < 1 || M < 1 || D < 1) return GE2E_ERR_SHAPE;
     return (int)launch_centroids(E, B, N, M, D, cent, (hipStream_t)stream);
+}
+
+int ge2e_selftest_split_gemm(const float* A, const float* Bm, const float* G, float* X, float* GE, float* GC,
+                             void* stream) {
+    if (!A || !Bm || !G || !X || !GE || !GC) return GE2E_ERR_NULL;
+    return (int)launch_selftest_split(A, Bm, G, X, GE, GC, (hipStream_t)stream);
+}
+
+int ge2e_selftest_wave_ops(const float* x, float* out, void* stream) {
+    if (!x || !out) return GE2E_ERR_NULL;
+    return (int)launch_selftest_wave(x, out, (hipStream_t)stream);
 }
 
 }  // extern "C"
