@@ -78,6 +78,9 @@ __device__ __forceinline__ float quad_sum(float v) { v += dpp_f<DPP_XOR1>(v); v 
 __device__ __forceinline__ float quad_max(float v) {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); return v;
 }
+// sum / max over each aligned group of 8 lanes, result in all 8
+__device__ __forceinline__ float oct_sum(float v) { v = quad_sum(v); v += dpp_f<DPP_HALF_MIRROR>(v); return v; }
+__device__ __forceinline__ float oct_max(float v) { v = quad_max(v); return fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); }
 // sum / max over each aligned group of 16 lanes, result in all 16
 __device__ __forceinline__ float row16_sum(float v) {
     v = quad_sum(v); v += dpp_f<DPP_HALF_MIRROR>(v); v += dpp_f<DPP_MIRROR>(v); return v;
@@ -106,6 +109,10 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 __device__ __forceinline__ void quad_argmax(float& v, int& i) {
     argmax_merge(v, i, dpp_f<DPP_XOR1>(v), dpp_i<DPP_XOR1>(i));
     argmax_merge(v, i, dpp_f<DPP_XOR2>(v), dpp_i<DPP_XOR2>(i));
+}
+__device__ __forceinline__ void oct_argmax(float& v, int& i) {
+    quad_argmax(v, i);
+    argmax_merge(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));
 }
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     quad_argmax(v, i);

@@ -561,6 +561,14 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_f32_kernel(Problem p, Fused
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
                                 ST[(8 * gg + 4 * h + q) * APITCH + 32 * b + l31] = ge[a][b][4 * (gb + gg) + q];
+                    // Drain the staging stores before anything else issues.  Measured on MI355X with two
+                    // waves per SIMD in this epilogue: without the drain (pinned by the scheduling barriers)
+                    // the compiler recycles the accumulator registers that feed these ds_write2_b32 a few
+                    // instructions later and, under LDS-store contention from the partner wave, ~5 % of the
+                    // launches stored clobbered values (4 lanes x 4 rows at a time; bitwise test caught it).
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll

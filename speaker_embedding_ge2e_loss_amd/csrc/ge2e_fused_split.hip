@@ -1,20 +1,32 @@
-// GE2E_IMPL_FUSED_SPLIT: same one-workgroup-per-batch, three-sweep structure as
-// ge2e_fused_split.hip (read that file's header first), with the three contractions on the fp16
-// matrix cores at fp32-grade accuracy: operands are held in LDS as fp16 hi + lo images and every
-// product is hi.hi + hi.lo + lo.hi in an fp32 accumulator (ge2e_split_gemm.hpp) -- 3/16 of the
-// cost of v_mfma_f32_32x32x2_f32.  Everything outside the contractions (norms, softmax, the
-// gradient algebra, the epilogue) stays fp32 on the VALU.
+// GE2E_IMPL_FUSED_SPLIT: one workgroup per batch, three sweeps over E like ge2e_fused_f32.hip
+// (read that file's header first), with two structural differences:
+//
+//  1. The three contractions run on the fp16 matrix cores at fp32-grade accuracy: operands live
+//     in LDS as fp16 hi + lo images and every product is hi.hi + hi.lo + lo.hi in an fp32
+//     accumulator (ge2e_split_gemm.hpp) -- 3/16 of the cost of v_mfma_f32_32x32x2_f32.  The same
+//     image serves a contraction along its rows (ds_read_b128 fragments: X = CH . ET^T) and along
+//     its columns (ds_read_b64_tr_b16 fragments: gE = G . CH, gC = G^T . ET).  Everything outside
+//     the contractions (norms, softmax, gradient algebra, epilogue) is fp32 on the VALU.
+//  2. 512 threads = 8 waves = two per SIMD.  Once the matrix work shrank 5x the kernel was bound by
+//     VALU phases issuing from a single wave per SIMD (one instruction per 4 cycles); two waves per
+//     SIMD double the vector issue rate and hide each other's LDS / memory latency.  Every VALU
+//     phase splits its rows over 8 waves; the gradient contractions give each wave a 32 x 64
+//     block (two waves share a SIMD's matrix pipe); X (four 32 x 32 tiles) stays on waves 0-3.
 //
 //   LDS (D=256: 159 KB)            fp16 images, pitch D+8 halfs (16-B aligned rows, b128 conflict-free)
 //     CHh, CHl [64][D+8]   unit centroids * 2^8, hi / lo
 //     ETh, ETl [64][D+8]   the tile's unit embeddings * 2^8, hi / lo  (fp32 gC staging in finalize)
 //     U        18 KB       union: S [64][68] fp32 (similarities)  |  Gh, Gl [64][72] fp16 (G_off * 2^8)
-//                                 |  the epilogue's 4 x [16][68] fp32 staging blocks
+//                                 |  the epilogue's 8 x [8][68] fp32 staging blocks
 //     KJ [6][D], RS [64][8], CST [64][4] fp32
 //
-// The same image serves a contraction along its rows (ds_read_b128 fragments: X = CH . ET^T) and
-// along its columns (ds_read_b64_tr_b16 fragments: gE = G . CH, gC = G^T . ET).  The operand of
-// the gradient contractions is G_off = dL/dS (in [0,1]); w is applied to the accumulators.
+// Leave-one-out statistics come out of the similarity tile instead of extra dot products: the
+// own-speaker column of X is c-hat_j . e-hat_r, so  e.s_j = X |s_j| |e|,
+//   e.u = (e.s_j - |e|^2)/(M-1),  |u|^2 = (|s_j|^2 - 2 e.s_j + |e|^2)/(M-1)^2.
+// (u = 0 exactly, i.e. the other M-1 utterances summing to zero, is where this form loses digits
+// against the reference's explicit u; GE2E_IMPL_GENERIC keeps the explicit form.)
+// The operand of the gradient contractions is G_off = dL/dS (in [0,1]); w is applied to the
+// accumulators.
 #include "ge2e_common.hpp"
 #include "ge2e_fused.hpp"
 #include "ge2e_split_gemm.hpp"
@@ -27,9 +39,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TR = 64;      // rows per tile
 constexpr int NC = 64;      // centroid slots
-constexpr int APITCH = 68;  // AT row pitch (floats): 16-B aligned rows, b128 reads conflict-free
-constexpr int MAX_SPT = 6;  // speakers per tile cap (KJ rows; 8 would not fit the LDS budget)
+constexpr int APITCH = 68;  // S / staging row pitch (floats)
 constexpr int GP = 72;      // G image row pitch (halfs)
+constexpr int MAX_SPT = 6;  // speakers per tile cap (KJ rows; 8 would not fit the LDS budget)
+constexpr int NWAVE = 8;
 constexpr unsigned OOB = 0x7FFFFF00u;  // lane offset that is out of range of every buffer here
 
 // RS / stashR columns
@@ -42,7 +55,6 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 __device__ __forceinline__ float4 scale4(const float4& a, float s) {
     return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
 }
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -55,9 +67,6 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff,
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
-
-// unit_stats with the common case (norm above the cosine eps) on v_rsq_f32 + one Newton step
-// instead of sqrt and two IEEE divisions; the clamped case keeps the exact slow path.
 __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
     if (sq > eps_cos * eps_cos && sq < 1e30f) {
         float r = __builtin_amdgcn_rsqf(sq);
@@ -68,16 +77,26 @@ __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& 
         unit_stats(sq, eps_cos, rn, kappa);
     }
 }
+// write 4 scaled values as fp16 hi / lo at the same (row, col) of two images
+__device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
+    h4 hi, lo;
+    split4(x, hi, lo);
+    *reinterpret_cast<h4*>(hi_img + off) = hi;
+    *reinterpret_cast<h4*>(lo_img + off) = lo;
+}
+__device__ __forceinline__ float4 get_join4(const _Float16* hi_img, const _Float16* lo_img, int off) {
+    return join4(*reinterpret_cast<const h4*>(hi_img + off), *reinterpret_cast<const h4*>(lo_img + off));
+}
 
 }  // namespace
 
 size_t fused_split_lds_bytes(int D) {
     const int PH = D + 8;
-    return (size_t)4 * 64 * PH * 2 + (size_t)2 * 64 * GP * 2 + (size_t)(MAX_SPT * D + TR * 8 + NC * 4 + 16) * sizeof(float);
+    return (size_t)4 * 64 * PH * 2 + (size_t)2 * 64 * GP * 2 + (size_t)(MAX_SPT * D + TR * 8 + NC * 4 + 32) * sizeof(float);
 }
 
 template <int NCH>  // D = 64 * NCH
-__global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, FusedWs wsl) {
+__global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, FusedWs wsl) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D + 4;    // fp32 pitch of the gC staging that reuses the ET images in finalize
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
     _Float16* const CHl = CHh + NC * PH;
     _Float16* const ETh = CHl + NC * PH;
     _Float16* const ETl = ETh + TR * PH;
-    float* const ET = reinterpret_cast<float*>(ETh);          // [64][P] fp32 view (finalize only)
+    float* const GCS = reinterpret_cast<float*>(ETh);          // [64][P] fp32 view (finalize only)
     float* const AT = reinterpret_cast<float*>(ETl + TR * PH); // U region as S / staging: [64][68] fp32
     _Float16* const Gh = reinterpret_cast<_Float16*>(AT);      // U region as G images
     _Float16* const Gl = Gh + TR * GP;
@@ -97,20 +116,23 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
     float* const RED = CST + NC * 4;
     static_assert(2 * TR * GP * 2 >= TR * APITCH * 4, "U region must hold the fp32 S tile");
     static_assert(2 * TR * PH * 2 >= NC * P * 4, "ET images must hold the fp32 gC staging");
+
     const int N = p.N, M = p.M, NM = N * M;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const int d4 = 4 * lane;          // whole-wave row passes: this lane's 4 consecutive columns
     const bool dact = d4 < D;
     const int sub = lane >> 4;        // tile staging: 16 lanes per row, 4 rows per wave-instruction
     const int l16 = lane & 15;
+    const int kh = wid >> 2;          // gradient contractions: 32-row (or 32-centroid) half
+    const int sl = wid & 3;           //                        64-column slice of d
+    const bool slice_on = 64 * sl < D;
 
     const int spt = wsl.spt;          // speakers per tile
     const int ntiles = wsl.ntiles;
-    // workspace slice of this workgroup; byte offsets inside it
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws + (size_t)blockIdx.x * wsl.stride, ws_bytes);
     const unsigned offA = (unsigned)(wsl.stash_a * 4), offR = (unsigned)(wsl.stash_rs * 4);
@@ -121,11 +143,9 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
     const float fM = (float)M, inv_m = 1.0f / (float)M, inv_m1 = 1.0f / (float)(M - 1);
     const bool contrast = p.variant == 1;
     const bool want_grad = p.dE != nullptr;
-    const bool slice_on = 64 * wid < D;  // this wave owns columns [64 wid, 64 wid + 64) in GEMM 2/3
 
-    // lane offsets (bytes) of the two access shapes
-    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                    // one row per wave
-    const unsigned vtile = (unsigned)((16 * wid + sub) * D + 4 * l16) * 4u;  // 4 rows per wave, + g*4 rows
+    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                   // one row per wave
+    const unsigned vtile = (unsigned)((8 * wid + sub) * D + 4 * l16) * 4u;  // 4 rows per wave, + g*4 rows
 
     GE2E_PROF_DECL(10)
     for (int bi = blockIdx.x; bi < p.B; bi += gridDim.x) {
@@ -133,15 +153,14 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
         const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
                                                       want_grad ? (unsigned)NM * ROWB : 0u);
 
-        // ================= sweep 1: speaker sums -> unit centroids in LDS =================
-        // Each wave streams the rows of a contiguous quarter of the speakers, one row per
-        // wave-instruction, through a 32-row register ring (32 KB per wave in flight).
+        // ================= sweep 1: speaker sums -> unit centroid images =====================
+        // each wave streams the rows of a contiguous eighth of the speakers through a 16-row ring
         {
-            const int per_w = (N + 3) >> 2;
+            const int per_w = (N + NWAVE - 1) / NWAVE;
             const int jb = min(wid * per_w, N), je = min(jb + per_w, N);
             const int nr = (je - jb) * M;
             const unsigned base = (unsigned)(jb * M) * ROWB;
-            constexpr int RING = 32;
+            constexpr int RING = 16;
             float4 ring[RING];
 #pragma unroll
             for (int u = 0; u < RING; ++u)
@@ -157,61 +176,52 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
                         if (++cnt == M) {
                             const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
                             const float sq = wave_sum(dot4(c, c));
+                            const float ss = wave_sum(dot4(s, s));
                             float rn, kap;
                             unit_stats(sq, eps_cos, rn, kap);
-                            if (dact) {
-                                h4 hi, lo;
-                                split4(scale4(c, rn * kSplitScale), hi, lo);
-                                *reinterpret_cast<h4*>(CHh + j * PH + d4) = hi;
-                                *reinterpret_cast<h4*>(CHl + j * PH + d4) = lo;
-                            }
-                            if (lane == 0) {
-                                CST[j * 4 + 0] = rn;          // 1 / max(|c|, eps)
-                                CST[j * 4 + 1] = kap;
-                                CST[j * 4 + 2] = fM / rn;     // s_j = c-hat_j * (M * max(|c|, eps))
-                            }
+                            if (dact) put_split4(CHh, CHl, j * PH + d4, scale4(c, rn * kSplitScale));
+                            if (lane == 0)  // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
+                                *reinterpret_cast<float4*>(CST + j * 4) = make_float4(rn, kap, fM / rn, ss);
                             s = zero4(); cnt = 0; ++j;
                         }
                     }
                     ring[u] = bload4(rsE, vrow, base + (unsigned)min(row + RING, max(nr - 1, 0)) * ROWB);
                 }
             }
-            for (int jz = N + wid; jz < NC; jz += 4) {        // unused centroid slots stay zero
+            for (int jz = N + wid; jz < NC; jz += NWAVE) {     // unused centroid slots stay zero
                 if (dact) {
                     *reinterpret_cast<h4*>(CHh + jz * PH + d4) = h4{0, 0, 0, 0};
                     *reinterpret_cast<h4*>(CHl + jz * PH + d4) = h4{0, 0, 0, 0};
                 }
-                if (lane == 0) { CST[jz * 4 + 0] = 0.f; CST[jz * 4 + 1] = 0.f; CST[jz * 4 + 2] = 0.f; }
+                if (lane == 0) *reinterpret_cast<float4*>(CST + jz * 4) = zero4();
             }
         }
         __syncthreads();
         GE2E_PROF(0);
 
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        f32x16 gc[2][2];  // dL/d c-hat accumulator: [k half][d half of this wave's 64-column slice]
+        f32x16 gc[2];  // dL/d c-hat accumulator: centroids 32 kh.., columns 64 sl + 32 b..
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gc[a][b][i] = 0.f;
+            for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
 
-        // tile rows in registers: v[g][c] = row 16 wid + 4 g + sub, columns 64 c + 4 l16 .. +3;
+        // tile rows in registers: v[g][c] = row 8 wid + 4 g + sub, columns 64 c + 4 l16 .. +3;
         // rows past the tile's last speaker get the out-of-range lane offset and read 0.
-        float4 v[4][NCH];
+        float4 v[2][NCH];
 #define GE2E_LOAD_ROWS(T)                                                                   \
     do {                                                                                    \
         const int j0_ = (T) * spt;                                                          \
         const int nrows_ = min(spt, N - j0_) * M;                                           \
         const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                    \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                     \
-            const unsigned vo_ = (16 * wid + 4 * g + sub < nrows_) ? vtile : OOB;           \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                     \
+            const unsigned vo_ = (8 * wid + 4 * g + sub < nrows_) ? vtile : OOB;            \
             _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                 \
                 v[g][c] = bload4(rsE, vo_, tb_ + (unsigned)(4 * g) * ROWB + 256u * c);      \
         }                                                                                   \
     } while (0)
 
-        // ================= sweep 2: similarity rows, loss, dL/dcos, gC =====================
+        // ================= sweep 2: similarity rows, loss, dL/dS, gC ========================
         GE2E_LOAD_ROWS(0);
         for (int t = 0; t < ntiles; ++t) {
             const int j0 = t * spt;
@@ -219,40 +229,24 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
             const int nrows = nspk * M;
             const int r0 = j0 * M;
 
-            // -- (a) normalise the prefetched rows, leave-one-out statistics -> ET, RS ---------
+            // -- (a) normalise the prefetched rows -> ET images; |e|^2, 1/|e| -> RS ---------------
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rl = 16 * wid + 4 * g + sub;
+            for (int g = 0; g < 2; ++g) {
+                const int rl = 8 * wid + 4 * g + sub;
                 const bool rv = rl < nrows;
-                const int j = j0 + (rv ? (int)(((float)rl + 0.5f) * inv_m) : 0);
-                const float sc = CST[j * 4 + 2] * kSplitInv;   // c-hat images carry 2^8
-                float ee = 0.f, uu = 0.f, eu = 0.f;
+                float ee = 0.f;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float4 ch = join4(*reinterpret_cast<const h4*>(CHh + j * PH + 64 * c + 4 * l16),
-                                            *reinterpret_cast<const h4*>(CHl + j * PH + 64 * c + 4 * l16));
-                    const float4 e = v[g][c];
-                    const float4 u = make_float4((ch.x * sc - e.x) * inv_m1, (ch.y * sc - e.y) * inv_m1,
-                                                 (ch.z * sc - e.z) * inv_m1, (ch.w * sc - e.w) * inv_m1);
-                    ee += dot4(e, e); uu += dot4(u, u); eu += dot4(e, u);
-                }
-                ee = row16_sum(ee); uu = row16_sum(uu); eu = row16_sum(eu);
-                float rne, ke, rnu, ku;
+                for (int c = 0; c < NCH; ++c) ee += dot4(v[g][c], v[g][c]);
+                ee = row16_sum(ee);
+                float rne, ke;
                 unit_stats_fast(ee, eps_cos, rne, ke);
-                unit_stats_fast(uu, eps_cos, rnu, ku);
                 if (!rv) rne = 0.f;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    h4 hi, lo;
-                    split4(scale4(v[g][c], rne * kSplitScale), hi, lo);
-                    *reinterpret_cast<h4*>(ETh + rl * PH + 64 * c + 4 * l16) = hi;
-                    *reinterpret_cast<h4*>(ETl + rl * PH + 64 * c + 4 * l16) = lo;
-                }
+                for (int c = 0; c < NCH; ++c)
+                    put_split4(ETh, ETl, rl * PH + 64 * c + 4 * l16, scale4(v[g][c], rne * kSplitScale));
                 if (l16 == 0) {
-                    float* rs = RS + rl * 8;
-                    *reinterpret_cast<float4*>(rs) = make_float4(rne, ke, rnu, ku);
-                    rs[4] = eu * rne * rnu;                 // cos(e, leave-one-out centroid)
-                    rs[5] = __int_as_float(rv ? j : -1);
+                    const int j = rv ? j0 + (int)(((float)rl + 0.5f) * inv_m) : -1;
+                    *reinterpret_cast<float4*>(RS + rl * 8) = make_float4(rne, ke, ee, __int_as_float(j));
                 }
             }
             __syncthreads();
@@ -260,8 +254,8 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
             GE2E_LOAD_ROWS(min(t + 1, ntiles - 1));
             GE2E_PROF(1);
 
-            // -- (b) X[k][r] = sum_d CH[k][d] ET[r][d]; wave (a,b) owns k-half a, r-half b ------
-            {
+            // -- (b) X[k][r] = sum_d CH[k][d] ET[r][d]; wave (a,b) of waves 0-3 owns k-half a, r-half b --
+            if (wid < 4) {
                 const int a = wid >> 1, b = wid & 1;
                 const f32x16 acc = gemm_nt_32x32<D>(CHh, CHl, PH, 32 * a, ETh, ETl, PH, 32 * b, lane);
                 // C layout: column (r) = lane&31, row (k) = (reg&3) + 8 (reg>>2) + 4 h
@@ -275,153 +269,154 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
             __syncthreads();
             GE2E_PROF(2);
 
-            // -- (c) per row: S = w (cos + eps) + b, loss, G = dL/dS -----------------------------
-            // 4 lanes per row, 16 centroids per lane: row reductions are two DPP quad steps.
+            // -- (c) per row: leave-one-out stats, S = w (cos + eps) + b, loss, G = dL/dS ---------
+            // 8 lanes per row, 8 centroids per lane: row reductions are three DPP steps.
             {
-                const int rl = 16 * wid + (lane >> 2);
-                const int qk = lane & 3;
-                const float4 rs0 = *reinterpret_cast<const float4*>(RS + rl * 8);  // rne ke rnu ku
-                const float cosd = RS[rl * 8 + 4];
-                const int j = __float_as_int(RS[rl * 8 + 5]);
+                const int rl = 8 * wid + (lane >> 3);
+                const int qk = lane & 7;
+                const float4 rs0 = *reinterpret_cast<const float4*>(RS + rl * 8);  // rne ke ee j
+                const float rne = rs0.x, ke = rs0.y, ee = rs0.z;
+                const int j = __float_as_int(rs0.w);
                 const bool rv = j >= 0;
-                const float rne = rs0.x, ke = rs0.y, rnu = rs0.z, ku = rs0.w;
-                float c0[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(AT + rl * APITCH + 16 * qk + 4 * i);
-                    c0[4 * i] = t4.x; c0[4 * i + 1] = t4.y; c0[4 * i + 2] = t4.z; c0[4 * i + 3] = t4.w;
+                const int jc = rv ? j : 0;
+                const float4 cs = *reinterpret_cast<const float4*>(CST + jc * 4);  // rn kap |s| |s|^2
+                const float xo = AT[rl * APITCH + jc];          // c-hat_j . e-hat_r
+                const float rne1 = rv ? rne : 1.0f;
+                const float es = xo * cs.z / rne1;               // e . s_j
+                const float eu = (es - ee) * inv_m1;
+                const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+                float rnu, ku;
+                unit_stats_fast(uu, eps_cos, rnu, ku);
+                const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+                float c0[8];
+                {
+                    const float4 t0 = *reinterpret_cast<const float4*>(AT + rl * APITCH + 8 * qk);
+                    const float4 t1 = *reinterpret_cast<const float4*>(AT + rl * APITCH + 8 * qk + 4);
+                    c0[0] = t0.x; c0[1] = t0.y; c0[2] = t0.z; c0[3] = t0.w;
+                    c0[4] = t1.x; c0[5] = t1.y; c0[6] = t1.z; c0[7] = t1.w;
                 }
-                const int jrel = j - 16 * qk;  // own-speaker column relative to this lane's 16
+                const int jrel = j - 8 * qk;  // own-speaker column relative to this lane's 8
 #pragma unroll
-                for (int i = 0; i < 16; ++i) if (i == jrel) c0[i] = cosd;
+                for (int i = 0; i < 8; ++i) if (i == jrel) c0[i] = cosd;
                 const float sjj = w * (cosd + eps) + bias;
-                float sv[16], g[16];
+                float sv[8], g[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sv[i] = (16 * qk + i < N) ? w * (c0[i] + eps) + bias : -INFINITY;
+                for (int i = 0; i < 8; ++i) sv[i] = (8 * qk + i < N) ? w * (c0[i] + eps) + bias : -INFINITY;
                 float per;
                 if (!contrast) {
                     float mx = sv[0];
 #pragma unroll
-                    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
-                    mx = fmaxf(quad_max(mx), log_eps);
+                    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, sv[i]);
+                    mx = fmaxf(oct_max(mx), log_eps);
                     float zoff = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
+                    for (int i = 0; i < 8; ++i) {
                         g[i] = __expf(sv[i] - mx);  // exp(-inf) = 0 for padded centroids
                         if (i != jrel) zoff += g[i];
                     }
-                    zoff = quad_sum(zoff) + __expf(log_eps - mx);
+                    zoff = oct_sum(zoff) + __expf(log_eps - mx);
                     const float z = zoff + __expf(sjj - mx);
                     per = (mx - sjj) + __logf(z);
                     const float rz = 1.0f / z;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) g[i] = (i == jrel) ? -zoff * rz : g[i] * rz;  // 1 - p_jj = z_off / z
+                    for (int i = 0; i < 8; ++i) g[i] = (i == jrel) ? -zoff * rz : g[i] * rz;  // 1 - p_jj = z_off / z
                 } else {
                     float best = -INFINITY; int besti = 0x7fffffff;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (i != jrel && sv[i] > best) { best = sv[i]; besti = 16 * qk + i; }
-                    quad_argmax(best, besti);
+                    for (int i = 0; i < 8; ++i)
+                        if (i != jrel && sv[i] > best) { best = sv[i]; besti = 8 * qk + i; }
+                    oct_argmax(best, besti);
                     const float pos = 1.0f / (1.0f + __expf(-sjj));
                     const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
                     per = 1.0f - pos + neg;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        g[i] = (i == jrel) ? -pos * (1.0f - pos) : ((16 * qk + i == besti) ? neg * (1.0f - neg) : 0.f);
+                    for (int i = 0; i < 8; ++i)
+                        g[i] = (i == jrel) ? -pos * (1.0f - pos) : ((8 * qk + i == besti) ? neg * (1.0f - neg) : 0.f);
                 }
                 float coef = 0.f, ad = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (!rv || 16 * qk + i >= N) g[i] = 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    if (!rv || 8 * qk + i >= N) g[i] = 0.f;
                     dw_acc += g[i] * (c0[i] + eps);
                     db_acc += g[i];
                     coef += g[i] * c0[i];           // (dL/d e-hat) . e-hat / w, own-speaker term included
                     if (i == jrel) { ad = g[i]; g[i] = 0.f; }
                 }
-                coef = w * quad_sum(coef);
-                ad = w * quad_sum(ad);              // dL/dcos on the own-speaker column
+                coef = w * oct_sum(coef);
+                ad = w * oct_sum(ad);               // dL/dcos on the own-speaker column
                 // the S tile and the G images share the U region: every lane has its S values in
                 // registers by now; wait for all of them before the region is rewritten
                 __syncthreads();
-                const float rne1 = rv ? rne : 1.0f;
-                const float rho = rnu * inv_m1;
-                const float c2 = rho * (ad * rne1 + ad * ku * cosd * rnu * inv_m1);
                 {
-                    h4 hi[4], lo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        split4(make_float4(g[4 * i] * kSplitScale, g[4 * i + 1] * kSplitScale,
-                                           g[4 * i + 2] * kSplitScale, g[4 * i + 3] * kSplitScale), hi[i], lo[i]);
-                    const h8 h0 = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const h8 h1 = __builtin_shufflevector(hi[2], hi[3], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const h8 l0 = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const h8 l1 = __builtin_shufflevector(lo[2], lo[3], 0, 1, 2, 3, 4, 5, 6, 7);
-                    *reinterpret_cast<h8*>(Gh + rl * GP + 16 * qk) = h0;
-                    *reinterpret_cast<h8*>(Gh + rl * GP + 16 * qk + 8) = h1;
-                    *reinterpret_cast<h8*>(Gl + rl * GP + 16 * qk) = l0;
-                    *reinterpret_cast<h8*>(Gl + rl * GP + 16 * qk + 8) = l1;
+                    h4 hi0, lo0, hi1, lo1;
+                    split4(make_float4(g[0] * kSplitScale, g[1] * kSplitScale, g[2] * kSplitScale, g[3] * kSplitScale), hi0, lo0);
+                    split4(make_float4(g[4] * kSplitScale, g[5] * kSplitScale, g[6] * kSplitScale, g[7] * kSplitScale), hi1, lo1);
+                    const h8 hh = __builtin_shufflevector(hi0, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const h8 ll = __builtin_shufflevector(lo0, lo1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    *reinterpret_cast<h8*>(Gh + rl * GP + 8 * qk) = hh;
+                    *reinterpret_cast<h8*>(Gl + rl * GP + 8 * qk) = ll;
                     // stash: [tile][hi 64x64 | lo 64x64] halfs, unpadded (16 KB per tile)
-                    const unsigned va = (unsigned)(t * (TR * NC * 4) + (rl * NC + 16 * qk) * 2);
-                    bstore4(rsW, va, offA, __builtin_bit_cast(float4, h0));
-                    bstore4(rsW, va, offA + 16u, __builtin_bit_cast(float4, h1));
-                    bstore4(rsW, va, offA + TR * NC * 2, __builtin_bit_cast(float4, l0));
-                    bstore4(rsW, va, offA + TR * NC * 2 + 16u, __builtin_bit_cast(float4, l1));
+                    const unsigned va = (unsigned)(t * (TR * NC * 4) + (rl * NC + 8 * qk) * 2);
+                    bstore4(rsW, va, offA, __builtin_bit_cast(float4, hh));
+                    bstore4(rsW, va, offA + TR * NC * 2, __builtin_bit_cast(float4, ll));
                 }
                 if (rv && qk == 0) {
                     loss_acc += per;
                     if (p.per) p.per[(size_t)bi * NM + r0 + rl] = per;
                 }
                 {
+                    // dE_r = w gE rne + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header)
+                    const float rho = rnu * inv_m1;
+                    const float c2 = rho * (ad * rne1 + ad * ku * cosd * rnu * inv_m1);
                     const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
                     const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
                     const float beta = -ad * rnu * ku * cosd * rho;
-                    const float c2s = rv ? c2 * CST[(rv ? j : 0) * 4 + 2] : 0.f;
                     const unsigned vr = (qk == 0) ? (unsigned)((t * TR + rl) * 32) : OOB;
-                    bstore4(rsW, vr, offR, make_float4(rne, c1, c2s, alpha * inv_m1));
+                    bstore4(rsW, vr, offR, make_float4(rne, c1, rv ? c2 * cs.z : 0.f, alpha * inv_m1));
                     bstore4(rsW, vr, offR + 16u, make_float4(beta * inv_m1, __int_as_float(j), 0.f, 0.f));
                 }
             }
             __syncthreads();
             GE2E_PROF(3);
 
-            // -- (d) gC[k][d] += sum_r G_off[r][k] ET[r][d]; wave owns a 64-column slice of d -------
-            if (slice_on && want_grad) gemm_tn_64x64(Gh, Gl, GP, 0, ETh, ETl, PH, 64 * wid, lane, gc);
+            // -- (d) gC[k][d] += sum_r G_off[r][k] ET[r][d]; wave: centroids 32 kh.., columns 64 sl.. ---
+            if (slice_on && want_grad) gemm_tn_32x64(Gh, Gl, GP, 32 * kh, ETh, ETl, PH, 64 * sl, lane, gc);
             __syncthreads();
             GE2E_PROF(4);
         }
 
-        // ---- batch scalars: fixed-order reduction over the 4 waves ---------------------------
+        // ---- batch scalars: fixed-order reduction over the 8 waves ---------------------------
         loss_acc = wave_sum(loss_acc);
         dw_acc = wave_sum(dw_acc);
         db_acc = wave_sum(db_acc);
-        if (lane == 0) { RED[wid] = loss_acc; RED[4 + wid] = dw_acc; RED[8 + wid] = db_acc; }
+        if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
         __syncthreads();
         if (tid == 0) {
-            if (p.loss) p.loss[bi] = (RED[0] + RED[1]) + (RED[2] + RED[3]);
-            if (p.dw) p.dw[bi] = (RED[4] + RED[5]) + (RED[6] + RED[7]);
-            if (p.db) p.db[bi] = (RED[8] + RED[9]) + (RED[10] + RED[11]);
+            float l = 0.f, a = 0.f, c = 0.f;
+#pragma unroll
+            for (int i = 0; i < NWAVE; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
+            if (p.loss) p.loss[bi] = l;
+            if (p.dw) p.dw[bi] = a;
+            if (p.db) p.db[bi] = c;
         }
         if (!want_grad) { __syncthreads(); continue; }
 
-        // ---- gC -> LDS (reusing ET) -> through the centroid norm -> dc / M in the workspace ----
+        // ---- gC -> LDS (fp32, over the ET images) -> through the centroid norm -> dc / M ----------
         if (slice_on) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int k = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        ET[k * P + 64 * wid + 32 * b + l31] = gc[a][b][i] * (w * kSplitInv2);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int k = 32 * kh + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    GCS[k * P + 64 * sl + 32 * b + l31] = gc[b][i] * (w * kSplitInv2);
+                }
         }
         __syncthreads();
-        for (int k = wid; k < N; k += 4) {
+        for (int k = wid; k < N; k += NWAVE) {
             float4 g = zero4(), c = g;
             if (dact) {
-                g = *reinterpret_cast<const float4*>(ET + k * P + d4);
-                c = scale4(join4(*reinterpret_cast<const h4*>(CHh + k * PH + d4),
-                                 *reinterpret_cast<const h4*>(CHl + k * PH + d4)), kSplitInv);
+                g = *reinterpret_cast<const float4*>(GCS + k * P + d4);
+                c = scale4(get_join4(CHh, CHl, k * PH + d4), kSplitInv);
             }
             const float coef = wave_sum(dot4(g, c));
             const float rn = CST[k * 4 + 0], kap = CST[k * 4 + 1];
@@ -432,29 +427,23 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
         __syncthreads();
         GE2E_PROF(5);
 
-        // ================= sweep 3: gE = A' . CH, epilogue -> dE ===========================
-        // prefetch group of a tile: dc rows of its speakers (this wave's: j0 + wid, j0 + wid + 4),
-        // the e rows, the stashed A' tile and row scalars.  (macro: arrays captured by a lambda land
-        // in scratch memory with a vmcnt(0) drain per element)
-        float4 a4_0, a4_1, a4_2, a4_3, r4, dcm_0, dcm_1;
-        float rne_0, rne_1, rne_2, rne_3;
+        // ================= sweep 3: gE = G_off . CH, epilogue -> dE ===========================
+        // prefetch group of a tile: the dc row of this wave's speaker (j0 + wid), the e rows, the
+        // stashed G images and row scalars (macro, not a lambda: captured arrays go to scratch)
+        float4 a4_0, a4_1, r4, dcm_0;
+        float rne_0, rne_1;
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
         dcm_0 = bload4(rsW, vrow, offDC + (unsigned)min(t_ * spt + wid, N - 1) * ROWB);               \
-        dcm_1 = bload4(rsW, vrow, offDC + (unsigned)min(t_ * spt + wid + 4, N - 1) * ROWB);           \
         GE2E_LOAD_ROWS(t_);                                                                           \
         const unsigned ta_ = offA + (unsigned)t_ * (TR * NC * 4);                                     \
         a4_0 = bload4(rsW, (unsigned)tid * 16u, ta_);                                                 \
-        a4_1 = bload4(rsW, (unsigned)tid * 16u, ta_ + 4096u);                                         \
-        a4_2 = bload4(rsW, (unsigned)tid * 16u, ta_ + 8192u);                                         \
-        a4_3 = bload4(rsW, (unsigned)tid * 16u, ta_ + 12288u);                                        \
+        a4_1 = bload4(rsW, (unsigned)tid * 16u, ta_ + TR * NC * 2);                                   \
         const unsigned tr_ = offR + (unsigned)t_ * (TR * 32);                                         \
         r4 = bload4(rsW, (unsigned)(tid & 127) * 16u, tr_);                                           \
-        rne_0 = bload1(rsW, (unsigned)(16 * wid + sub) * 32u, tr_);                                   \
-        rne_1 = bload1(rsW, (unsigned)(16 * wid + sub) * 32u, tr_ + 128u);                            \
-        rne_2 = bload1(rsW, (unsigned)(16 * wid + sub) * 32u, tr_ + 256u);                            \
-        rne_3 = bload1(rsW, (unsigned)(16 * wid + sub) * 32u, tr_ + 384u);                            \
+        rne_0 = bload1(rsW, (unsigned)(8 * wid + sub) * 32u, tr_);                                    \
+        rne_1 = bload1(rsW, (unsigned)(8 * wid + sub) * 32u, tr_ + 128u);                             \
     } while (0)
 
         GE2E_LOAD_TILE3(0);
@@ -463,103 +452,88 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_split_kernel(Problem p, Fus
             const int nspk = min(spt, N - j0);
             const int nrows = nspk * M;
             const int r0 = j0 * M;
-            // -- (a) stage the prefetched tile: e-hat, A', row scalars ---------------------------
+            // -- (a) stage the prefetched tile: e-hat images, G images, row scalars ----------------
             {
                 if (tid < TR * 2) reinterpret_cast<float4*>(RS)[tid] = r4;
-                // stashed G images: 1024 float4 = hi [64][64] halfs then lo; float4 f holds 8 halfs of row f / 8
-                {
-                    const int r = tid >> 3, c8 = (tid & 7) * 8;
-                    *reinterpret_cast<float4*>(Gh + r * GP + c8) = a4_0;          // float4 tid
-                    *reinterpret_cast<float4*>(Gh + (r + 32) * GP + c8) = a4_1;   // float4 tid + 256
-                    *reinterpret_cast<float4*>(Gl + r * GP + c8) = a4_2;          // float4 tid + 512
-                    *reinterpret_cast<float4*>(Gl + (r + 32) * GP + c8) = a4_3;   // float4 tid + 768
-                }
-                const float rne_g[4] = {rne_0, rne_1, rne_2, rne_3};
+                // stashed images: float4 f holds 8 halfs of row f / 8 (512 float4 per image)
+                *reinterpret_cast<float4*>(Gh + (tid >> 3) * GP + (tid & 7) * 8) = a4_0;
+                *reinterpret_cast<float4*>(Gl + (tid >> 3) * GP + (tid & 7) * 8) = a4_1;
+                const float rne_g[2] = {rne_0, rne_1};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int rl = 16 * wid + 4 * g + sub;
+                for (int g = 0; g < 2; ++g) {
+                    const int rl = 8 * wid + 4 * g + sub;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) {  // pad rows: v = 0 and rne = 0
-                        h4 hi, lo;
-                        split4(scale4(v[g][c], rne_g[g] * kSplitScale), hi, lo);
-                        *reinterpret_cast<h4*>(ETh + rl * PH + 64 * c + 4 * l16) = hi;
-                        *reinterpret_cast<h4*>(ETl + rl * PH + 64 * c + 4 * l16) = lo;
-                    }
+                    for (int c = 0; c < NCH; ++c)  // pad rows: v = 0 and rne = 0
+                        put_split4(ETh, ETl, rl * PH + 64 * c + 4 * l16, scale4(v[g][c], rne_g[g] * kSplitScale));
                 }
             }
-            const float4 dcm_cur[2] = {dcm_0, dcm_1};
+            const float4 dcm_cur = dcm_0;
             __syncthreads();
             GE2E_LOAD_TILE3(min(t + 1, ntiles - 1));
             GE2E_PROF(6);
-            // -- (b) per-speaker constant rows KJ_j = dc_j/M + sum_i (c3_i e-hat_i + c4_i s_j) ----
-#pragma unroll
-            for (int jq = 0; jq < 2; ++jq) {
-                const int jl = wid + 4 * jq;
-                const int j = j0 + jl;
-                if (dact && jl < nspk) {
-                    float4 acc = dcm_cur[jq];
-                    float bsum = 0.f;
-                    for (int i = 0; i < M; ++i) {
-                        const int rl = jl * M + i;
-                        const float c3 = RS[rl * 8 + R_C3] * kSplitInv;
-                        bsum += RS[rl * 8 + R_C4];
-                        const float4 e = join4(*reinterpret_cast<const h4*>(ETh + rl * PH + d4),
-                                               *reinterpret_cast<const h4*>(ETl + rl * PH + d4));
-                        acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
-                    }
-                    const float4 c = join4(*reinterpret_cast<const h4*>(CHh + j * PH + d4),
-                                           *reinterpret_cast<const h4*>(CHl + j * PH + d4));
-                    const float bs = bsum * CST[j * 4 + 2] * kSplitInv;
-                    *reinterpret_cast<float4*>(KJ + jl * D + d4) =
-                        make_float4(acc.x + bs * c.x, acc.y + bs * c.y, acc.z + bs * c.z, acc.w + bs * c.w);
+            // -- (b) per-speaker constant rows KJ_j = dc_j/M + sum_i (c3_i e-hat_i + c4_i s_j); one per wave --
+            if (dact && wid < nspk) {
+                const int jl = wid, j = j0 + jl;
+                float4 acc = dcm_cur;
+                float bsum = 0.f;
+                for (int i = 0; i < M; ++i) {
+                    const int rl = jl * M + i;
+                    const float c3 = RS[rl * 8 + R_C3] * kSplitInv;
+                    bsum += RS[rl * 8 + R_C4];
+                    const float4 e = get_join4(ETh, ETl, rl * PH + d4);
+                    acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
                 }
+                const float4 c = get_join4(CHh, CHl, j * PH + d4);
+                const float bs = bsum * CST[j * 4 + 2] * kSplitInv;
+                *reinterpret_cast<float4*>(KJ + jl * D + d4) =
+                    make_float4(acc.x + bs * c.x, acc.y + bs * c.y, acc.z + bs * c.z, acc.w + bs * c.w);
             }
-            // -- (c) gE[r][d] = sum_k G_off[r][k] CH[k][d]; wave owns its 64-column slice ---------
-            f32x16 ge[2][2];
+            // -- (c) gE[r][d] = sum_k G_off[r][k] CH[k][d]; wave: rows 32 kh.., columns 64 sl.. ----------
+            f32x16 ge[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) ge[a][b][i] = 0.f;
-            if (slice_on) gemm_nn_64x64(Gh, Gl, GP, CHh, CHl, PH, 64 * wid, lane, ge);
-            __syncthreads();  // KJ complete, every wave is done reading AT
+                for (int i = 0; i < 16; ++i) ge[b][i] = 0.f;
+            if (slice_on) gemm_nn_32x64(Gh, Gl, GP, 32 * kh, CHh, CHl, PH, 64 * sl, lane, ge);
+            __syncthreads();  // KJ complete, every wave is done reading the G images
             GE2E_PROF(7);
             // -- (d) epilogue: accumulator layout (lane = column) -> row layout through this wave's
-            //        16 x 64 staging block (AT is dead now), then 16-byte stores, 4 rows x 256 B
-            //        per wave-instruction:  dE = w gE rne + c1 e-hat + c2 s_j + KJ_j
+            //        8 x 64 staging block (the G images are dead now), then 16-byte stores, 4 rows x
+            //        256 B per wave-instruction:  dE = w gE rne + c1 e-hat + c2 s_j + KJ_j
             if (slice_on) {
-                float* ST = AT + wid * (16 * APITCH);
-                const unsigned vst = (unsigned)(sub * D + 64 * wid + 4 * l16) * 4u;
+                float* ST = AT + wid * (8 * APITCH);
+                const int col = 64 * sl + 4 * l16;
+                const unsigned vst = (unsigned)(sub * D + col) * 4u;
 #pragma unroll
-                for (int cq = 0; cq < 4; ++cq) {      // four chunks of 16 rows
-                    const int a = cq >> 1, gb = 2 * (cq & 1);
+                for (int g = 0; g < 4; ++g) {      // four chunks of 8 rows: 32 kh + 8 g + (4 h + q)
 #pragma unroll
-                    for (int gg = 0; gg < 2; ++gg)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b)
-                                ST[(8 * gg + 4 * h + q) * APITCH + 32 * b + l31] = ge[a][b][4 * (gb + gg) + q];
+                        for (int b = 0; b < 2; ++b) ST[(4 * h + q) * APITCH + 32 * b + l31] = ge[b][4 * g + q];
+                    // Drain the staging stores before anything else issues.  Measured on MI355X with two
+                    // waves per SIMD in this epilogue: without the drain (pinned by the scheduling barriers)
+                    // the compiler recycles the accumulator registers that feed these ds_write2_b32 a few
+                    // instructions later and, under LDS-store contention from the partner wave, ~5 % of the
+                    // launches stored clobbered values (4 lanes x 4 rows at a time; bitwise test caught it).
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
+                    for (int ps = 0; ps < 2; ++ps) {
                         const int rloc = 4 * ps + sub;
-                        const int rl = 16 * cq + rloc;
+                        const int rl = 32 * kh + 8 * g + rloc;
                         const bool rv = rl < nrows;
                         const float4 acc = *reinterpret_cast<const float4*>(ST + rloc * APITCH + 4 * l16);
                         const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 8);  // rne c1 c2s c3
                         const int j = rv ? __float_as_int(RS[rl * 8 + R_J]) : j0;
                         const float ra = rs.x * (w * kSplitInv2), re = rs.y * kSplitInv, rc = rs.z * kSplitInv;
-                        const int col = 64 * wid + 4 * l16;
-                        const float4 e = join4(*reinterpret_cast<const h4*>(ETh + rl * PH + col),
-                                               *reinterpret_cast<const h4*>(ETl + rl * PH + col));
-                        const float4 cj = join4(*reinterpret_cast<const h4*>(CHh + j * PH + col),
-                                                *reinterpret_cast<const h4*>(CHl + j * PH + col));
+                        const float4 e = get_join4(ETh, ETl, rl * PH + col);
+                        const float4 cj = get_join4(CHh, CHl, j * PH + col);
                         const float4 kj = *reinterpret_cast<const float4*>(KJ + (j - j0) * D + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
-                        bstore4(rsG, rv ? vst : OOB, (unsigned)(r0 + 16 * cq + 4 * ps) * ROWB,
+                        bstore4(rsG, rv ? vst : OOB, (unsigned)(r0 + 32 * kh + 8 * g + 4 * ps) * ROWB,
                                 make_float4(acc.x * ra + e.x * re + cj.x * rc + kj.x, acc.y * ra + e.y * re + cj.y * rc + kj.y,
                                             acc.z * ra + e.z * re + cj.z * rc + kj.z, acc.w * ra + e.w * re + cj.w * rc + kj.w));
                     }
@@ -605,7 +579,7 @@ static hipError_t launch_nch(const Problem& p, const FusedWs& L, size_t lds, hip
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_fused_split_kernel<NCH>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(ge2e_fused_split_kernel<NCH>, dim3(fused_split_grid(p.B)), dim3(256), lds, stream, p, L);
+    hipLaunchKernelGGL(ge2e_fused_split_kernel<NCH>, dim3(fused_split_grid(p.B)), dim3(512), lds, stream, p, L);
     return hipGetLastError();
 }
 

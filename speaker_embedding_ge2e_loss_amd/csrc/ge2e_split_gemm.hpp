@@ -135,4 +135,33 @@ __device__ __forceinline__ void gemm_nn_64x64(const _Float16* Ah, const _Float16
     }
 }
 
+// 8-wave variants: one 32-wide block of A against two 32-wide blocks of B (32 x 64 per wave).
+// out[b] += sum_{k < 64} A[k][am0 + m] * B[k][bn0 + 32 b + n]   (both through the transposing load)
+__device__ __forceinline__ void gemm_tn_32x64(const _Float16* Ah, const _Float16* Al, int pa, int am0,
+                                              const _Float16* Bh, const _Float16* Bl, int pb, int bn0,
+                                              int lane, f32x16 (&out)[2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const h8 ah = frag_tr(Ah, pa, 16 * s, am0, lane), al = frag_tr(Al, pa, 16 * s, am0, lane);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            out[b] = mfma3(ah, al, frag_tr(Bh, pb, 16 * s, bn0 + 32 * b, lane),
+                           frag_tr(Bl, pb, 16 * s, bn0 + 32 * b, lane), out[b]);
+    }
+}
+// out[b] += sum_{k < 64} A[ar0 + m][k] * B[k][bn0 + 32 b + n]   (A: ds_read_b128 rows, B: transposing load)
+__device__ __forceinline__ void gemm_nn_32x64(const _Float16* Ah, const _Float16* Al, int pa, int ar0,
+                                              const _Float16* Bh, const _Float16* Bl, int pb, int bn0,
+                                              int lane, f32x16 (&out)[2]) {
+    const int off_a = (ar0 + (lane & 31)) * pa + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const h8 ah = frag_row(Ah + off_a + 16 * s), al = frag_row(Al + off_a + 16 * s);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            out[b] = mfma3(ah, al, frag_tr(Bh, pb, 16 * s, bn0 + 32 * b, lane),
+                           frag_tr(Bl, pb, 16 * s, bn0 + 32 * b, lane), out[b]);
+    }
+}
+
 }  // namespace ge2e
