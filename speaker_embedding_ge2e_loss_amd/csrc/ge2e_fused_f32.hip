@@ -71,8 +71,9 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+template <int AUX = 0>  // cache-policy bits: 2 = nt (streaming)
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
 // unit_stats with the common case (norm above the cosine eps) on v_rsq_f32 + one Newton step
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_f32_kernel(Problem p, Fused
                         const float4 e = *reinterpret_cast<const float4*>(ET + rl * P + 64 * wid + 4 * l16);
                         const float4 kj = *reinterpret_cast<const float4*>(KJ + jl * D + 64 * wid + 4 * l16);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
-                        bstore4(rsG, rv ? vst : OOB, (unsigned)(r0 + 16 * cq + 4 * ps) * ROWB,
+                        bstore4<2>(rsG, rv ? vst : OOB, (unsigned)(r0 + 16 * cq + 4 * ps) * ROWB,
                                 make_float4(acc.x * rne + e.x * c1 + kj.x, acc.y * rne + e.y * c1 + kj.y,
                                             acc.z * rne + e.z * c1 + kj.z, acc.w * rne + e.w * c1 + kj.w));
                     }
