@@ -46,7 +46,6 @@ constexpr int NWAVE = 8;
 constexpr unsigned OOB = 0x7FFFFF00u;  // lane offset that is out of range of every buffer here
 
 // RS / stashR columns
-constexpr int R_RNE = 0, R_C1 = 1, R_C2S = 2, R_C3 = 3, R_C4 = 4, R_J = 5;
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws + (size_t)blockIdx.x * wsl.stride, ws_bytes);
     const unsigned offA = (unsigned)(wsl.stash_a * 4), offR = (unsigned)(wsl.stash_rs * 4);
-    const unsigned offDC = (unsigned)(wsl.dcm * 4);
+    const unsigned offDC = (unsigned)(wsl.dcm * 4), offKP = (unsigned)(wsl.dump * 4);
 
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
     const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
@@ -378,20 +377,46 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                     if (p.per) p.per[(size_t)bi * NM + r0 + rl] = per;
                 }
                 {
-                    // dE_r = w gE rne + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header)
+                    // dE_r = w gE rne + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header), stored for
+                    // sweep 3 as the ready-made coefficients of acc, of the RAW row e and of c-hat_j images
                     const float rho = rnu * inv_m1;
                     const float c2 = rho * (ad * rne1 + ad * ku * cosd * rnu * inv_m1);
                     const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
                     const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
                     const float beta = -ad * rnu * ku * cosd * rho;
-                    const unsigned vr = (qk == 0) ? (unsigned)((t * TR + rl) * 32) : OOB;
-                    bstore4(rsW, vr, offR, make_float4(rne, c1, rv ? c2 * cs.z : 0.f, alpha * inv_m1));
-                    bstore4(rsW, vr, offR + 16u, make_float4(beta * inv_m1, __int_as_float(j), 0.f, 0.f));
+                    if (qk == 0) {   // c3, c4: coefficients of e-hat_i and s_j in the speaker's KJ row
+                        RS[rl * 8 + 4] = rv ? alpha * inv_m1 : 0.f;
+                        RS[rl * 8 + 5] = rv ? beta * inv_m1 : 0.f;
+                    }
+                    const unsigned vr = (qk == 0) ? (unsigned)((t * TR + rl) * 16) : OOB;
+                    bstore4(rsW, vr, offR, make_float4(rne * (w * kSplitInv2), c1 * rne,
+                                                       rv ? c2 * cs.z * kSplitInv : 0.f, __int_as_float(j)));
                 }
             }
             __syncthreads();
             GE2E_PROF(3);
 
+            // -- (d0) per-speaker rows KJP_j = sum_i (c3_i e-hat_i + c4_i s_j), one speaker per wave; they
+            //         are completed with dc_j / M in finalize, so sweep 3 never needs the e-hat images
+            if (want_grad && wid < nspk) {
+                const int jl = wid, j = j0 + jl;
+                float4 acc = zero4();
+                float bsum = 0.f;
+                for (int i = 0; i < M; ++i) {
+                    const int rl = jl * M + i;
+                    const float c3 = RS[rl * 8 + 4] * kSplitInv;
+                    bsum += RS[rl * 8 + 5];
+                    if (dact) {
+                        const float4 e = get_join4(ETh, ETl, rl * PH + d4);
+                        acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
+                    }
+                }
+                float4 c = zero4();
+                if (dact) c = get_join4(CHh, CHl, j * PH + d4);
+                const float bs = bsum * CST[j * 4 + 2] * kSplitInv;
+                bstore4(rsW, vrow, offKP + (unsigned)j * ROWB,
+                        make_float4(acc.x + bs * c.x, acc.y + bs * c.y, acc.z + bs * c.z, acc.w + bs * c.w));
+            }
             // -- (d) gC[k][d] += sum_r G_off[r][k] ET[r][d]; wave: centroids 32 kh.., columns 64 sl.. ---
             if (slice_on && want_grad) gemm_tn_32x64(Gh, Gl, GP, 32 * kh, ETh, ETl, PH, 64 * sl, lane, gc);
             __syncthreads();
@@ -431,32 +456,40 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                 g = *reinterpret_cast<const float4*>(GCS + k * P + d4);
                 c = scale4(get_join4(CHh, CHl, k * PH + d4), kSplitInv);
             }
+            const float4 kp = bload4(rsW, vrow, offKP + (unsigned)k * ROWB);
             const float coef = wave_sum(dot4(g, c));
             const float rn = CST[k * 4 + 0], kap = CST[k * 4 + 1];
             const float f = kap * coef, sc = rn / fM;
-            bstore4(rsW, vrow, offDC + (unsigned)k * ROWB,
-                    make_float4((g.x - f * c.x) * sc, (g.y - f * c.y) * sc, (g.z - f * c.z) * sc, (g.w - f * c.w) * sc));
+            bstore4(rsW, vrow, offDC + (unsigned)k * ROWB,   // the complete per-speaker row KJ_k
+                    make_float4((g.x - f * c.x) * sc + kp.x, (g.y - f * c.y) * sc + kp.y,
+                                (g.z - f * c.z) * sc + kp.z, (g.w - f * c.w) * sc + kp.w));
         }
         __syncthreads();
         GE2E_PROF(5);
 
         // ================= sweep 3: gE = G_off . CH, epilogue -> dE ===========================
-        // prefetch group of a tile: the dc row of this wave's speaker (j0 + wid), the e rows, the
-        // stashed G images and row scalars (macro, not a lambda: captured arrays go to scratch)
-        float4 a4_0, a4_1, r4, dcm_0;
-        float rne_0, rne_1;
+        // Nothing here needs the e-hat images: the raw rows are read straight into the epilogue's own
+        // layout (row 32 kh + 8 g + 4 ps + sub, columns 64 sl + 4 l16) and enter dE with the stored
+        // coefficient c1 |e|^-1.  Prefetch group of a tile: those rows, the stashed G images, the
+        // row scalars and this wave's speaker row KJ_j (macro, not a lambda: captured arrays go to scratch).
+        float4 a4_0, a4_1, r4, kj_0;
+        float4 ev[4][2];
+        const unsigned vep = slice_on ? (unsigned)((32 * kh + sub) * D + 64 * sl + 4 * l16) * 4u : OOB;
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
-        dcm_0 = bload4(rsW, vrow, offDC + (unsigned)min(t_ * spt + wid, N - 1) * ROWB);               \
-        GE2E_LOAD_ROWS_AUX(t_, GE2E_AUX_E3);                                                          \
+        const int j0_ = t_ * spt;                                                                     \
+        const int nrows_ = min(spt, N - j0_) * M;                                                     \
+        const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                              \
+        kj_0 = bload4(rsW, vrow, offDC + (unsigned)min(j0_ + wid, N - 1) * ROWB);                     \
         const unsigned ta_ = offA + (unsigned)t_ * (TR * NC * 4);                                     \
         a4_0 = bload4(rsW, (unsigned)tid * 16u, ta_);                                                 \
         a4_1 = bload4(rsW, (unsigned)tid * 16u, ta_ + TR * NC * 2);                                   \
-        const unsigned tr_ = offR + (unsigned)t_ * (TR * 32);                                         \
-        r4 = bload4(rsW, (unsigned)(tid & 127) * 16u, tr_);                                           \
-        rne_0 = bload1(rsW, (unsigned)(8 * wid + sub) * 32u, tr_);                                    \
-        rne_1 = bload1(rsW, (unsigned)(8 * wid + sub) * 32u, tr_ + 128u);                             \
+        r4 = bload4(rsW, (unsigned)(tid & 63) * 16u, offR + (unsigned)t_ * (TR * 16));                \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                 \
+            _Pragma("unroll") for (int ps = 0; ps < 2; ++ps)                                          \
+                ev[g][ps] = bload4<GE2E_AUX_E3>(rsE, (32 * kh + 8 * g + 4 * ps + sub < nrows_) ? vep : OOB, \
+                                                tb_ + (unsigned)(8 * g + 4 * ps) * ROWB);             \
     } while (0)
 
         GE2E_LOAD_TILE3(0);
@@ -465,42 +498,21 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
             const int nspk = min(spt, N - j0);
             const int nrows = nspk * M;
             const int r0 = j0 * M;
-            // -- (a) stage the prefetched tile: e-hat images, G images, row scalars ----------------
-            {
-                if (tid < TR * 2) reinterpret_cast<float4*>(RS)[tid] = r4;
-                // stashed images: float4 f holds 8 halfs of row f / 8 (512 float4 per image)
-                *reinterpret_cast<float4*>(Gh + (tid >> 3) * GP + (tid & 7) * 8) = a4_0;
-                *reinterpret_cast<float4*>(Gl + (tid >> 3) * GP + (tid & 7) * 8) = a4_1;
-                const float rne_g[2] = {rne_0, rne_1};
+            // -- (a) stage the prefetched G images, row scalars (ra c1e rc j) and speaker rows ------
+            if (tid < TR) reinterpret_cast<float4*>(RS)[tid] = r4;   // RS as [64][4] in sweep 3
+            // stashed images: float4 f holds 8 halfs of row f / 8 (512 float4 per image)
+            *reinterpret_cast<float4*>(Gh + (tid >> 3) * GP + (tid & 7) * 8) = a4_0;
+            *reinterpret_cast<float4*>(Gl + (tid >> 3) * GP + (tid & 7) * 8) = a4_1;
+            if (dact && wid < nspk) *reinterpret_cast<float4*>(KJ + wid * D + d4) = kj_0;
+            // the rows of THIS tile move out of the prefetch registers before the next group is requested
+            float4 ec[4][2];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const int rl = 8 * wid + 4 * g + sub;
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c)  // pad rows: v = 0 and rne = 0
-                        put_split4(ETh, ETl, rl * PH + 64 * c + 4 * l16, scale4(v[g][c], rne_g[g] * kSplitScale));
-                }
-            }
-            const float4 dcm_cur = dcm_0;
+                for (int ps = 0; ps < 2; ++ps) ec[g][ps] = ev[g][ps];
             __syncthreads();
             GE2E_LOAD_TILE3(min(t + 1, ntiles - 1));
             GE2E_PROF(6);
-            // -- (b) per-speaker constant rows KJ_j = dc_j/M + sum_i (c3_i e-hat_i + c4_i s_j); one per wave --
-            if (dact && wid < nspk) {
-                const int jl = wid, j = j0 + jl;
-                float4 acc = dcm_cur;
-                float bsum = 0.f;
-                for (int i = 0; i < M; ++i) {
-                    const int rl = jl * M + i;
-                    const float c3 = RS[rl * 8 + R_C3] * kSplitInv;
-                    bsum += RS[rl * 8 + R_C4];
-                    const float4 e = get_join4(ETh, ETl, rl * PH + d4);
-                    acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
-                }
-                const float4 c = get_join4(CHh, CHl, j * PH + d4);
-                const float bs = bsum * CST[j * 4 + 2] * kSplitInv;
-                *reinterpret_cast<float4*>(KJ + jl * D + d4) =
-                    make_float4(acc.x + bs * c.x, acc.y + bs * c.y, acc.z + bs * c.z, acc.w + bs * c.w);
-            }
             // -- (c) gE[r][d] = sum_k G_off[r][k] CH[k][d]; wave: rows 32 kh.., columns 64 sl.. ----------
             f32x16 ge[2];
 #pragma unroll
@@ -508,11 +520,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ge[b][i] = 0.f;
             if (slice_on) gemm_nn_32x64(Gh, Gl, GP, 32 * kh, CHh, CHl, PH, 64 * sl, lane, ge);
-            __syncthreads();  // KJ complete, every wave is done reading the G images
+            __syncthreads();  // every wave is done reading the G images
             GE2E_PROF(7);
             // -- (d) epilogue: accumulator layout (lane = column) -> row layout through this wave's
             //        8 x 64 staging block (the G images are dead now), then 16-byte stores, 4 rows x
-            //        256 B per wave-instruction:  dE = w gE rne + c1 e-hat + c2 s_j + KJ_j
+            //        256 B per wave-instruction:  dE = ra acc + c1e e + rc c-hat_j + KJ_j
             if (slice_on) {
                 float* ST = AT + wid * (8 * APITCH);
                 const int col = 64 * sl + 4 * l16;
@@ -539,16 +551,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         const int rl = 32 * kh + 8 * g + rloc;
                         const bool rv = rl < nrows;
                         const float4 acc = *reinterpret_cast<const float4*>(ST + rloc * APITCH + 4 * l16);
-                        const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 8);  // rne c1 c2s c3
-                        const int j = rv ? __float_as_int(RS[rl * 8 + R_J]) : j0;
-                        const float ra = rs.x * (w * kSplitInv2), re = rs.y * kSplitInv, rc = rs.z * kSplitInv;
-                        const float4 e = get_join4(ETh, ETl, rl * PH + col);
+                        const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 4);  // ra c1e rc j
+                        const int j = rv ? __float_as_int(rs.w) : j0;
+                        const float4 e = ec[g][ps];
                         const float4 cj = get_join4(CHh, CHl, j * PH + col);
                         const float4 kj = *reinterpret_cast<const float4*>(KJ + (j - j0) * D + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
                         bstore4<GE2E_AUX_DE>(rsG, rv ? vst : OOB, (unsigned)(r0 + 32 * kh + 8 * g + 4 * ps) * ROWB,
-                                make_float4(acc.x * ra + e.x * re + cj.x * rc + kj.x, acc.y * ra + e.y * re + cj.y * rc + kj.y,
-                                            acc.z * ra + e.z * re + cj.z * rc + kj.z, acc.w * ra + e.w * re + cj.w * rc + kj.w));
+                                make_float4(acc.x * rs.x + e.x * rs.y + cj.x * rs.z + kj.x, acc.y * rs.x + e.y * rs.y + cj.y * rs.z + kj.y,
+                                            acc.z * rs.x + e.z * rs.y + cj.z * rs.z + kj.z, acc.w * rs.x + e.w * rs.y + cj.w * rs.z + kj.w));
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -573,11 +584,11 @@ FusedWs fused_split_layout(int N, int M, int D) {
     if (spt > N) spt = N;
     L.spt = spt;
     L.ntiles = (N + spt - 1) / spt;
-    L.stash_a = 0;
-    L.stash_rs = L.stash_a + (size_t)L.ntiles * TR * NC;
-    L.dcm = L.stash_rs + (size_t)L.ntiles * TR * 8;
-    L.dump = L.dcm + (size_t)NC * D;
-    L.stride = align_up(L.dump, 64);
+    L.stash_a = 0;                                             // [ntiles][2][64][64] halfs
+    L.stash_rs = L.stash_a + (size_t)L.ntiles * TR * NC;       // [ntiles][64][4] floats
+    L.dcm = L.stash_rs + (size_t)L.ntiles * TR * 4;            // [64][D] complete speaker rows KJ
+    L.dump = L.dcm + (size_t)NC * D;                           // [64][D] partial speaker rows KJP
+    L.stride = align_up(L.dump + (size_t)NC * D, 64);
     return L;
 }
 
