@@ -8,7 +8,7 @@ namespace ge2e {
 struct FusedWs {
     int spt;       // whole speakers per 64-row tile
     int ntiles;    // tiles per batch
-    size_t stash_a, stash_rs, dcm, dump, stride;
+    size_t stash_a, stash_rs, dcm, dump, sums, stride;
 };
 
 bool fused_f32_supports(int N, int M, int D);

@@ -72,8 +72,13 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff,
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 template <int AUX = 0>  // cache-policy bits: 2 = nt (streaming)
+// NOTE the offset of a 16-byte store goes entirely into the VGPR (soffset = immediate 0).  With a
+// REGISTER soffset LLVM assumes the "VMEM store > 64 bit, then VALU write of its data VGPRs" hazard does
+// not exist and lets the very next instruction overwrite the store's data registers; on gfx950 with two
+// waves per SIMD that clobbered ~5 % of launches (4 rows x 64 columns at a time, always the younger
+// wave of a SIMD).  With an immediate soffset the hazard recognizer inserts the wait state itself.
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, AUX);
 }
 
 // unit_stats with the common case (norm above the cosine eps) on v_rsq_f32 + one Newton step
@@ -562,14 +567,6 @@ __global__ __launch_bounds__(256, 1) void ge2e_fused_f32_kernel(Problem p, Fused
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
                                 ST[(8 * gg + 4 * h + q) * APITCH + 32 * b + l31] = ge[a][b][4 * (gb + gg) + q];
-                    // Drain the staging stores before anything else issues.  Measured on MI355X with two
-                    // waves per SIMD in this epilogue: without the drain (pinned by the scheduling barriers)
-                    // the compiler recycles the accumulator registers that feed these ds_write2_b32 a few
-                    // instructions later and, under LDS-store contention from the partner wave, ~5 % of the
-                    // launches stored clobbered values (4 lanes x 4 rows at a time; bitwise test caught it).
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll

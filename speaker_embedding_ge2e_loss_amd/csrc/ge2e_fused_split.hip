@@ -75,8 +75,13 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff,
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 template <int AUX = 0>
+// NOTE the offset of a 16-byte store goes entirely into the VGPR (soffset = immediate 0).  With a
+// REGISTER soffset LLVM assumes the "VMEM store > 64 bit, then VALU write of its data VGPRs" hazard does
+// not exist and lets the very next instruction overwrite the store's data registers; on gfx950 with two
+// waves per SIMD that clobbered ~5 % of launches (4 rows x 64 columns at a time, always the younger
+// wave of a SIMD).  With an immediate soffset the hazard recognizer inserts the wait state itself.
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, AUX);
 }
 __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
     if (sq > eps_cos * eps_cos && sq < 1e30f) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws + (size_t)blockIdx.x * wsl.stride, ws_bytes);
     const unsigned offA = (unsigned)(wsl.stash_a * 4), offR = (unsigned)(wsl.stash_rs * 4);
-    const unsigned offDC = (unsigned)(wsl.dcm * 4), offKP = (unsigned)(wsl.dump * 4);
+    const unsigned offDC = (unsigned)(wsl.dcm * 4), offKP = (unsigned)(wsl.dump * 4), offSM = (unsigned)(wsl.sums * 4);
 
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
     const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
@@ -159,17 +164,32 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const unsigned vtile = (unsigned)((8 * wid + sub) * D + 4 * l16) * 4u;  // 4 rows per wave, + g*4 rows
 
     GE2E_PROF_DECL(10)
+    bool have_sums = false;   // speaker sums of the current batch already sit in the workspace
     for (int bi = blockIdx.x; bi < p.B; bi += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
         const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
                                                       want_grad ? (unsigned)NM * ROWB : 0u);
 
         // ================= sweep 1: speaker sums -> unit centroid images =====================
-        // each wave streams the rows of a contiguous eighth of the speakers through a 16-row ring
-        {
-            const int per_w = (N + NWAVE - 1) / NWAVE;
-            const int jb = min(wid * per_w, N), je = min(jb + per_w, N);
-            const int nr = (je - jb) * M;
+        // Each wave owns a contiguous eighth of the speakers.  The first batch of this workgroup
+        // streams their rows through a 16-row ring; for every later batch the sums are already in the
+        // workspace: the previous batch's sweep 3 streamed these rows underneath its own compute
+        // (sweep 1 alone runs at the HBM rate and used to be 16 % of the kernel with nothing to overlap).
+        const int per_w = (N + NWAVE - 1) / NWAVE;
+        const int jb = min(wid * per_w, N), je = min(jb + per_w, N);
+        const int nr_w = (je - jb) * M;                      // rows this wave sums
+        auto finish_speaker = [&](int j, const float4& s) {
+            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float sq = wave_sum(dot4(c, c));
+            const float ss = wave_sum(dot4(s, s));
+            float rn, kap;
+            unit_stats(sq, eps_cos, rn, kap);
+            if (dact) put_split4(CHh, CHl, j * PH + d4, scale4(c, rn * kSplitScale));
+            if (lane == 0)  // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
+                *reinterpret_cast<float4*>(CST + j * 4) = make_float4(rn, kap, fM / rn, ss);
+        };
+        if (!have_sums) {
+            const int nr = nr_w;
             const unsigned base = (unsigned)(jb * M) * ROWB;
             constexpr int RING = 16;
             float4 ring[RING];
@@ -184,28 +204,25 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                     const int row = rb + u;
                     if (row < nr) {
                         s.x += ring[u].x; s.y += ring[u].y; s.z += ring[u].z; s.w += ring[u].w;
-                        if (++cnt == M) {
-                            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
-                            const float sq = wave_sum(dot4(c, c));
-                            const float ss = wave_sum(dot4(s, s));
-                            float rn, kap;
-                            unit_stats(sq, eps_cos, rn, kap);
-                            if (dact) put_split4(CHh, CHl, j * PH + d4, scale4(c, rn * kSplitScale));
-                            if (lane == 0)  // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
-                                *reinterpret_cast<float4*>(CST + j * 4) = make_float4(rn, kap, fM / rn, ss);
-                            s = zero4(); cnt = 0; ++j;
-                        }
+                        if (++cnt == M) { finish_speaker(j, s); s = zero4(); cnt = 0; ++j; }
                     }
                     ring[u] = bload4<GE2E_AUX_E1>(rsE, vrow, base + (unsigned)min(row + RING, max(nr - 1, 0)) * ROWB);
                 }
             }
-            for (int jz = N + wid; jz < NC; jz += NWAVE) {     // unused centroid slots stay zero
-                if (dact) {
-                    *reinterpret_cast<h4*>(CHh + jz * PH + d4) = h4{0, 0, 0, 0};
-                    *reinterpret_cast<h4*>(CHl + jz * PH + d4) = h4{0, 0, 0, 0};
-                }
-                if (lane == 0) *reinterpret_cast<float4*>(CST + jz * 4) = zero4();
+        } else {
+            float4 sums[8];                                   // per_w <= 8 because N <= 64
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sums[u] = bload4(rsW, vrow, offSM + (unsigned)min(jb + u, N - 1) * ROWB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (jb + u < je) finish_speaker(jb + u, sums[u]);
+        }
+        for (int jz = N + wid; jz < NC; jz += NWAVE) {     // unused centroid slots stay zero
+            if (dact) {
+                *reinterpret_cast<h4*>(CHh + jz * PH + d4) = h4{0, 0, 0, 0};
+                *reinterpret_cast<h4*>(CHl + jz * PH + d4) = h4{0, 0, 0, 0};
             }
+            if (lane == 0) *reinterpret_cast<float4*>(CST + jz * 4) = zero4();
         }
         __syncthreads();
         GE2E_PROF(0);
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
             if (p.dw) p.dw[bi] = a;
             if (p.db) p.db[bi] = c;
         }
-        if (!want_grad) { __syncthreads(); continue; }
+        if (!want_grad) { __syncthreads(); have_sums = false; continue; }
 
         // ---- gC -> LDS (fp32, over the ET images) -> through the centroid norm -> dc / M ----------
         if (slice_on) {
@@ -478,21 +495,58 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
-        const int j0_ = t_ * spt;                                                                     \
-        const int nrows_ = min(spt, N - j0_) * M;                                                     \
-        const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                              \
-        kj_0 = bload4(rsW, vrow, offDC + (unsigned)min(j0_ + wid, N - 1) * ROWB);                     \
+        kj_0 = bload4(rsW, vrow, offDC + (unsigned)min(t_ * spt + wid, N - 1) * ROWB);                \
         const unsigned ta_ = offA + (unsigned)t_ * (TR * NC * 4);                                     \
         a4_0 = bload4(rsW, (unsigned)tid * 16u, ta_);                                                 \
         a4_1 = bload4(rsW, (unsigned)tid * 16u, ta_ + TR * NC * 2);                                   \
         r4 = bload4(rsW, (unsigned)(tid & 63) * 16u, offR + (unsigned)t_ * (TR * 16));                \
+    } while (0)
+#define GE2E_LOAD_EROWS(T)                                                                            \
+    do {                                                                                              \
+        const int j0_ = (T) * spt;                                                                    \
+        const int nrows_ = min(spt, N - j0_) * M;                                                     \
+        const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                              \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                 \
             _Pragma("unroll") for (int ps = 0; ps < 2; ++ps)                                          \
                 ev[g][ps] = bload4<GE2E_AUX_E3>(rsE, (32 * kh + 8 * g + 4 * ps + sub < nrows_) ? vep : OOB, \
                                                 tb_ + (unsigned)(8 * g + 4 * ps) * ROWB);             \
     } while (0)
 
+        // the next batch of this workgroup: its rows are summed per speaker underneath this sweep
+        const int bnext = bi + gridDim.x;
+        const bool has_next = bnext < p.B;
+        const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E + (size_t)(has_next ? bnext : bi) * NM * D,
+                                                       has_next ? (unsigned)NM * ROWB : 0u);
+        const int nr2 = has_next ? nr_w : 0;
+        const unsigned base2 = (unsigned)(jb * M) * ROWB;
+        float4 ring2[8];
+        float4 s2 = zero4();
+        int cnt2 = 0, j2 = jb, rb2 = 0;
+#define GE2E_RING2_LOAD(ROW0)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                     \
+        ring2[u] = bload4<GE2E_AUX_E1>(rsE2, vrow, base2 + (unsigned)min((ROW0) + u, max(nr2 - 1, 0)) * ROWB)
+        // 8 rows per step; a finished speaker's sum goes to the workspace (wave-uniform branch: at most
+        // ceil(8 / M) + 1 stores per step, usually one or none)
+#define GE2E_RING2_STEP()                                                                             \
+    do {                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                               \
+            if (rb2 + u < nr2) {                                                                      \
+                s2.x += ring2[u].x; s2.y += ring2[u].y; s2.z += ring2[u].z; s2.w += ring2[u].w;       \
+                if (++cnt2 == M) {                                                                    \
+                    bstore4(rsW, vrow, offSM + (unsigned)j2 * ROWB, s2);                              \
+                    s2 = zero4(); cnt2 = 0; ++j2;                                                     \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+        rb2 += 8;                                                                                     \
+        GE2E_RING2_LOAD(rb2);                                                                         \
+    } while (0)
+
+        // prologue in the SAME relative order as inside the loop (group, ring, rows): the compiler
+        // sizes each counted vmcnt wait by the path with the fewest younger operations
         GE2E_LOAD_TILE3(0);
+        GE2E_RING2_LOAD(0);
+        GE2E_LOAD_EROWS(0);
         for (int t = 0; t < ntiles; ++t) {
             const int j0 = t * spt;
             const int nspk = min(spt, N - j0);
@@ -504,14 +558,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
             *reinterpret_cast<float4*>(Gh + (tid >> 3) * GP + (tid & 7) * 8) = a4_0;
             *reinterpret_cast<float4*>(Gl + (tid >> 3) * GP + (tid & 7) * 8) = a4_1;
             if (dact && wid < nspk) *reinterpret_cast<float4*>(KJ + wid * D + d4) = kj_0;
-            // the rows of THIS tile move out of the prefetch registers before the next group is requested
-            float4 ec[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) ec[g][ps] = ev[g][ps];
             __syncthreads();
-            GE2E_LOAD_TILE3(min(t + 1, ntiles - 1));
+            GE2E_LOAD_TILE3(min(t + 1, ntiles - 1));   // first: vmcnt retires in order, and the next (a) waits on these
+            GE2E_RING2_STEP();                         // next batch's rows: 8 summed, 8 requested (HBM latency)
             GE2E_PROF(6);
             // -- (c) gE[r][d] = sum_k G_off[r][k] CH[k][d]; wave: rows 32 kh.., columns 64 sl.. ----------
             f32x16 ge[2];
@@ -535,14 +584,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) ST[(4 * h + q) * APITCH + 32 * b + l31] = ge[b][4 * g + q];
-                    // Drain the staging stores before anything else issues.  Measured on MI355X with two
-                    // waves per SIMD in this epilogue: without the drain (pinned by the scheduling barriers)
-                    // the compiler recycles the accumulator registers that feed these ds_write2_b32 a few
-                    // instructions later and, under LDS-store contention from the partner wave, ~5 % of the
-                    // launches stored clobbered values (4 lanes x 4 rows at a time; bitwise test caught it).
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -553,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         const float4 acc = *reinterpret_cast<const float4*>(ST + rloc * APITCH + 4 * l16);
                         const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 4);  // ra c1e rc j
                         const int j = rv ? __float_as_int(rs.w) : j0;
-                        const float4 e = ec[g][ps];
+                        const float4 e = ev[g][ps];
                         const float4 cj = get_join4(CHh, CHl, j * PH + col);
                         const float4 kj = *reinterpret_cast<const float4*>(KJ + (j - j0) * D + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
@@ -565,9 +606,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            GE2E_LOAD_EROWS(min(t + 1, ntiles - 1));   // consumed by the next epilogue; same registers
             __syncthreads();
             GE2E_PROF(8);
         }
+        while (rb2 < nr2) GE2E_RING2_STEP();           // rows the tile loop did not cover (M * N/8 > 8 * ntiles)
+        have_sums = has_next;
     }
     GE2E_PROF_FLUSH(10)
 }
@@ -588,7 +632,8 @@ FusedWs fused_split_layout(int N, int M, int D) {
     L.stash_rs = L.stash_a + (size_t)L.ntiles * TR * NC;       // [ntiles][64][4] floats
     L.dcm = L.stash_rs + (size_t)L.ntiles * TR * 4;            // [64][D] complete speaker rows KJ
     L.dump = L.dcm + (size_t)NC * D;                           // [64][D] partial speaker rows KJP
-    L.stride = align_up(L.dump + (size_t)NC * D, 64);
+    L.sums = L.dump + (size_t)NC * D;                          // [64][D] speaker sums of the NEXT batch
+    L.stride = align_up(L.sums + (size_t)NC * D, 64);
     return L;
 }
 
