@@ -8,6 +8,7 @@
 #include "ge2e_generic.hpp"
 #include "ge2e_fused.hpp"
 #include "ge2e_selftest.hpp"
+#include "ge2e_tiled.hpp"
 
 using namespace ge2e;
 
@@ -23,10 +24,12 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)B; (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
-            return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_IMPL_GENERIC;
+            if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
+            return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;
         case GE2E_IMPL_FUSED_F32: return fused_f32_supports(N, M, D) ? GE2E_IMPL_FUSED_F32 : GE2E_ERR_IMPL;
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_ERR_IMPL;
+        case GE2E_IMPL_TILED: return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -36,6 +39,7 @@ size_t ws_bytes(int B, int N, int M, int D, int impl) {
         case GE2E_IMPL_GENERIC: return generic_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_FUSED_F32: return fused_f32_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_TILED: return tiled_workspace_bytes(B, N, M, D);
         default: return 0;
     }
 }
@@ -58,6 +62,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
         case GE2E_IMPL_GENERIC: err = launch_generic(p, (hipStream_t)stream); break;
         case GE2E_IMPL_FUSED_F32: err = launch_fused_f32(p, (hipStream_t)stream); break;
         case GE2E_IMPL_FUSED_SPLIT: err = launch_fused_split(p, (hipStream_t)stream); break;
+        case GE2E_IMPL_TILED: err = launch_tiled(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;

@@ -1,0 +1,515 @@
+// GE2E_IMPL_TILED: shapes whose centroids do not fit one workgroup's LDS (N > 64 or D > 256:
+// BASELINE configs 4 and 5).  Many workgroups per batch, six small kernels on one stream, the
+// three contractions as 64 x 64 x 64 LDS-tiled split-fp16 MFMA GEMMs (ge2e_split_gemm.hpp) over
+// operand images that are split ONCE into fp16 hi / lo planes in the workspace:
+//
+//   k_prep    per speaker : sums, c-hat -> CH images + fp32 copy; per row: 1/|e|, e-hat -> EH images
+//   k_sim     X = EH . CH^T                    tiles (64 rows x 64 centroids), K = D      (s3:64-70)
+//   k_rows    per row     : leave-one-out cosine from X's own column, S, loss, G_off -> GH images,
+//                           row coefficients of the gradient                              (s3:27, 115-127)
+//   k_gc      gC = GH^T . EH                   tiles (64 centroids x 64 d), K = all N*M rows
+//   k_spk     per speaker : gC through the centroid norm, + leave-one-out sums -> KJ rows
+//   k_ge      gE = GH . CH, epilogue dE = ra gE + c1e e + rc c-hat_j + KJ_j
+//   k_reduce  loss / dw / db: fixed-order sum of the per-row values
+//
+// Shapes: D % 64 == 0, D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
+// Same algebra and same split arithmetic as ge2e_fused_split.hip; config 5 is MFMA-bound
+// (SURVEY 8d), so the extra image traffic (L2 / Infinity-Cache resident) is not the limiter.
+#include "ge2e_common.hpp"
+#include "ge2e_split_gemm.hpp"
+#include "ge2e_tiled.hpp"
+
+namespace ge2e {
+
+namespace {
+
+constexpr int TP = 72;  // LDS tile pitch (halfs): 64 + 8
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 scale4(const float4& a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
+    if (sq > eps_cos * eps_cos && sq < 1e30f) {
+        float r = __builtin_amdgcn_rsqf(sq);
+        r = r * (1.5f - 0.5f * sq * r * r);
+        rn = r;
+        kappa = 1.0f;
+    } else {
+        unit_stats(sq, eps_cos, rn, kappa);
+    }
+}
+
+// 64 x 64 fp16 tile of a row-major global image (leading dimension ld halfs) -> LDS [64][TP];
+// rows >= rows_valid are zero.  256 threads, two 16-byte pieces each.
+__device__ __forceinline__ void stage_tile(const _Float16* g, size_t ld, int rows_valid, _Float16* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 3, c8 = (idx & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rows_valid) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + c8);
+        *reinterpret_cast<uint4*>(lds + row * TP + c8) = v;
+    }
+}
+
+struct Tiles {
+    _Float16 *Ah, *Al, *Bh, *Bl;
+};
+__device__ __forceinline__ Tiles carve_tiles(_Float16* base) {
+    return Tiles{base, base + 64 * TP, base + 2 * 64 * TP, base + 3 * 64 * TP};
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// k_prep: one wave per speaker.  D <= 1024: four float4 per lane cover a row.
+__global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave = (batch, speaker)
+    const int N = p.N, M = p.M, D = p.D;
+    if (gw >= p.B * N) return;
+    const int bi = gw / N, j = gw - bi * N;
+    const float* E = p.E + ((size_t)bi * N + j) * M * D;
+    const size_t NMp = (size_t)N * M;
+    _Float16* CHh = reinterpret_cast<_Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D;
+    _Float16* CHl = CHh + (size_t)N * D;
+    _Float16* EHh = reinterpret_cast<_Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D;
+    _Float16* EHl = EHh + NMp * D;
+    float* CHf = p.ws + L.chf + (size_t)bi * N * D;
+    float* CST = p.ws + L.cst + ((size_t)bi * N + j) * 4;
+    float* RST = p.ws + L.rst + ((size_t)bi * N + j) * M * 4;
+    const float fM = (float)M;
+    const int npass = (D + 255) >> 8;
+
+    float4 s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = 256 * c + 4 * lane;
+            if (c < npass && d < D) {
+                const float4 v = *reinterpret_cast<const float4*>(E + (size_t)i * D + d);
+                s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+            }
+        }
+    float sq = 0.f, ss = 0.f;   // |c|^2 with c = s / M formed first, like the reference; |s|^2 for the row stats
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 cc = make_float4(s[c].x / fM, s[c].y / fM, s[c].z / fM, s[c].w / fM);
+        sq += dot4(cc, cc);
+        ss += dot4(s[c], s[c]);
+    }
+    sq = wave_sum(sq);
+    ss = wave_sum(ss);
+    float rn, kap;
+    unit_stats(sq, p.eps_cos, rn, kap);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int d = 256 * c + 4 * lane;
+        if (c < npass && d < D) {
+            const float4 ch = make_float4(s[c].x / fM * rn, s[c].y / fM * rn, s[c].z / fM * rn, s[c].w / fM * rn);
+            *reinterpret_cast<float4*>(CHf + (size_t)j * D + d) = ch;
+            h4 hi, lo;
+            split4(scale4(ch, kSplitScale), hi, lo);
+            *reinterpret_cast<h4*>(CHh + (size_t)j * D + d) = hi;
+            *reinterpret_cast<h4*>(CHl + (size_t)j * D + d) = lo;
+        }
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(CST) = make_float4(rn, kap, fM / rn, ss);
+    // rows: 1/|e| and the e-hat images
+    for (int i = 0; i < M; ++i) {
+        float4 v[4];
+        float ee = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = 256 * c + 4 * lane;
+            v[c] = (c < npass && d < D) ? *reinterpret_cast<const float4*>(E + (size_t)i * D + d)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            ee += dot4(v[c], v[c]);
+        }
+        ee = wave_sum(ee);
+        float rne, ke;
+        unit_stats_fast(ee, p.eps_cos, rne, ke);
+        const size_t r = (size_t)j * M + i;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = 256 * c + 4 * lane;
+            if (c < npass && d < D) {
+                h4 hi, lo;
+                split4(scale4(v[c], rne * kSplitScale), hi, lo);
+                *reinterpret_cast<h4*>(EHh + r * D + d) = hi;
+                *reinterpret_cast<h4*>(EHl + r * D + d) = lo;
+            }
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(RST + (size_t)i * 4) = make_float4(rne, ke, ee, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per 64 x 64 tile, 4 waves as 2 x 2.
+__global__ __launch_bounds__(256) void ge2e_tiled_sim(Problem p, TiledWs L) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
+    const Tiles T = carve_tiles(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int N = p.N, D = p.D, NM = p.N * p.M;
+    const int rt = L.row_tiles, ct = L.cen_tiles;
+    int t = blockIdx.x;
+    const int kt = t % ct; t /= ct;
+    const int rtile = t % rt;
+    const int bi = t / rt;
+    const size_t NMp = (size_t)NM;
+    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * 64 * D;
+    const _Float16* EHl = EHh + NMp * D;
+    const _Float16* CHh = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * 64 * D;
+    const _Float16* CHl = CHh + (size_t)N * D;
+    const int rows_a = min(64, NM - rtile * 64), rows_b = min(64, N - kt * 64);
+    const int a = wid >> 1, b = wid & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kc = 0; kc < D; kc += 64) {
+        stage_tile(EHh + kc, D, rows_a, T.Ah, tid);
+        stage_tile(EHl + kc, D, rows_a, T.Al, tid);
+        stage_tile(CHh + kc, D, rows_b, T.Bh, tid);
+        stage_tile(CHl + kc, D, rows_b, T.Bl, tid);
+        __syncthreads();
+        const int oa = (32 * a + (lane & 31)) * TP + 8 * (lane >> 5);
+        const int ob = (32 * b + (lane & 31)) * TP + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = mfma3(frag_row(T.Ah + oa + 16 * s), frag_row(T.Al + oa + 16 * s),
+                        frag_row(T.Bh + ob + 16 * s), frag_row(T.Bl + ob + 16 * s), acc);
+        __syncthreads();
+    }
+    float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = rtile * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (r < NM) X[(size_t)r * L.npad + kt * 64 + 32 * b + l31] = acc[i] * kSplitInv2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rows: one wave per row; the row of X (<= 1024 centroids) lives in 16 registers per lane.
+__global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
+    const int lane = threadIdx.x & 63;
+    const size_t gr = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // global row
+    const int N = p.N, M = p.M, NM = N * M, npad = L.npad;
+    if (gr >= (size_t)p.B * NM) return;
+    const int bi = (int)(gr / NM), r = (int)(gr - (size_t)bi * NM), j = r / M;
+    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    const float eps = p.eps, log_eps = p.log_eps;
+    const float inv_m1 = 1.0f / (float)(M - 1);
+    const float* X = p.ws + L.x + ((size_t)bi * NM + r) * npad;
+    const float4 rst = *reinterpret_cast<const float4*>(p.ws + L.rst + gr * 4);      // rne ke ee
+    const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);  // rn kap |s| |s|^2
+    const float rne = rst.x, ke = rst.y, ee = rst.z;
+    const float xo = X[j];
+    const float es = xo * cs.z / rne;
+    const float eu = (es - ee) * inv_m1;
+    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+    float rnu, ku;
+    unit_stats_fast(uu, p.eps_cos, rnu, ku);
+    const float cosd = eu * rne * rnu;
+    const float sjj = w * (cosd + eps) + bias;
+    const int nch = npad >> 6;
+    float c0[16], g[16];
+    float mx = -INFINITY, best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        c0[c] = 0.f;
+        if (c < nch) {
+            const int k = 64 * c + lane;
+            c0[c] = (k == j) ? cosd : X[k];
+            if (k < N) {
+                const float s = w * (c0[c] + eps) + bias;
+                mx = fmaxf(mx, s);
+                if (k != j && s > best) { best = s; besti = k; }
+            }
+        }
+    }
+    float per;
+    if (p.variant == 0) {
+        mx = fmaxf(wave_max(mx), log_eps);
+        float zoff = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = 64 * c + lane;
+            g[c] = (c < nch && k < N) ? __expf(w * (c0[c] + eps) + bias - mx) : 0.f;
+            if (k != j) zoff += g[c];
+        }
+        zoff = wave_sum(zoff) + __expf(log_eps - mx);
+        const float z = zoff + __expf(sjj - mx);
+        per = (mx - sjj) + __logf(z);
+        const float rz = 1.0f / z;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) g[c] = (64 * c + lane == j) ? -zoff * rz : g[c] * rz;
+    } else {
+        wave_argmax(best, besti);
+        const float pos = 1.0f / (1.0f + __expf(-sjj));
+        const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
+        per = 1.0f - pos + neg;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = 64 * c + lane;
+            g[c] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+        }
+    }
+    float dwv = 0.f, dbv = 0.f, coef = 0.f, ad = 0.f;
+    _Float16* GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r * npad;
+    _Float16* GHl = GHh + (size_t)NM * npad;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < nch) {
+            const int k = 64 * c + lane;
+            float gv = (k < N) ? g[c] : 0.f;
+            dwv += gv * (c0[c] + eps);
+            dbv += gv;
+            coef += gv * c0[c];
+            if (k == j) { ad = gv; gv = 0.f; }
+            const float x = gv * kSplitScale;
+            const _Float16 hi = (_Float16)x;
+            unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, hi);
+            asm volatile("" : "+v"(hb));  // residual against the stored bits (see split4)
+            const _Float16 hi2 = __builtin_bit_cast(_Float16, (unsigned short)hb);
+            GHh[k] = hi2;
+            GHl[k] = (_Float16)(x - (float)hi2);
+        }
+    }
+    dwv = wave_sum(dwv); dbv = wave_sum(dbv);
+    coef = w * wave_sum(coef); ad = w * wave_sum(ad);
+    if (lane == 0) {
+        const float rho = rnu * inv_m1;
+        const float c2 = rho * (ad * rne + ad * ku * cosd * rnu * inv_m1);
+        const float c1 = (-ke * coef * rne - ad * rnu * inv_m1) - c2 / rne;
+        const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne);
+        const float beta = -ad * rnu * ku * cosd * rho;
+        float* rs = p.ws + L.rs + gr * 8;
+        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, c2 * cs.z, alpha * inv_m1);
+        *reinterpret_cast<float4*>(rs + 4) = make_float4(beta * inv_m1, per, dwv, dbv);
+        if (p.per) p.per[gr] = per;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (64 centroids x 64 d) tile,
+// looping over all row tiles of the batch; both operands through the transposing load.
+__global__ __launch_bounds__(256) void ge2e_tiled_gc(Problem p, TiledWs L) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
+    const Tiles T = carve_tiles(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int N = p.N, D = p.D, NM = p.N * p.M, npad = L.npad;
+    const int dtiles = D >> 6, ct = L.cen_tiles;
+    int t = blockIdx.x;
+    const int dt = t % dtiles; t /= dtiles;
+    const int kt = t % ct;
+    const int bi = t / ct;
+    const _Float16* GHh = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * 64;
+    const _Float16* GHl = GHh + (size_t)NM * npad;
+    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * 64;
+    const _Float16* EHl = EHh + (size_t)NM * D;
+    const int a = wid >> 1, b = wid & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int r0 = 0; r0 < NM; r0 += 64) {
+        const int rows = min(64, NM - r0);
+        stage_tile(GHh + (size_t)r0 * npad, npad, rows, T.Ah, tid);
+        stage_tile(GHl + (size_t)r0 * npad, npad, rows, T.Al, tid);
+        stage_tile(EHh + (size_t)r0 * D, D, rows, T.Bh, tid);
+        stage_tile(EHl + (size_t)r0 * D, D, rows, T.Bl, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = mfma3(frag_tr(T.Ah, TP, 16 * s, 32 * a, lane), frag_tr(T.Al, TP, 16 * s, 32 * a, lane),
+                        frag_tr(T.Bh, TP, 16 * s, 32 * b, lane), frag_tr(T.Bl, TP, 16 * s, 32 * b, lane), acc);
+        __syncthreads();
+    }
+    float* GC = p.ws + L.gc + (size_t)bi * N * D;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = kt * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (k < N) GC[(size_t)k * D + dt * 64 + 32 * b + l31] = acc[i] * kSplitInv2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_spk: one wave per speaker: dc_j / M (gC through the centroid norm) + the leave-one-out sums.
+__global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = p.N, M = p.M, D = p.D, NM = N * M;
+    if (gw >= p.B * N) return;
+    const int bi = gw / N, j = gw - bi * N;
+    const float w = p.w ? *p.w : p.w_imm;
+    const float fM = (float)M;
+    const float* GC = p.ws + L.gc + ((size_t)bi * N + j) * D;
+    const float* CHf = p.ws + L.chf + ((size_t)bi * N + j) * D;
+    const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);
+    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + (size_t)j * M * D;
+    const _Float16* EHl = EHh + (size_t)NM * D;
+    const float* RS = p.ws + L.rs + ((size_t)bi * NM + (size_t)j * M) * 8;
+    float* KJ = p.ws + L.kj + ((size_t)bi * N + j) * D;
+    const int npass = (D + 255) >> 8;
+    float4 g[4], c[4];
+    float coef = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d = 256 * q + 4 * lane;
+        g[q] = c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < npass && d < D) {
+            g[q] = scale4(*reinterpret_cast<const float4*>(GC + d), w);
+            c[q] = *reinterpret_cast<const float4*>(CHf + d);
+            coef += dot4(g[q], c[q]);
+        }
+    }
+    coef = wave_sum(coef);
+    const float f = cs.y * coef, sc = cs.x / fM;
+    float bsum = 0.f;
+    for (int i = 0; i < M; ++i) bsum += RS[i * 8 + 4];
+    const float bs = bsum * cs.z;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d = 256 * q + 4 * lane;
+        if (q < npass && d < D) {
+            float4 acc = make_float4((g[q].x - f * c[q].x) * sc + bs * c[q].x, (g[q].y - f * c[q].y) * sc + bs * c[q].y,
+                                     (g[q].z - f * c[q].z) * sc + bs * c[q].z, (g[q].w - f * c[q].w) * sc + bs * c[q].w);
+            for (int i = 0; i < M; ++i) {
+                const float c3 = RS[i * 8 + 3] * kSplitInv;
+                const float4 e = join4(*reinterpret_cast<const h4*>(EHh + (size_t)i * D + d),
+                                       *reinterpret_cast<const h4*>(EHl + (size_t)i * D + d));
+                acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
+            }
+            *reinterpret_cast<float4*>(KJ + d) = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (64 rows x 64 d) tile, then the epilogue.
+__global__ __launch_bounds__(256) void ge2e_tiled_ge(Problem p, TiledWs L) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
+    const Tiles T = carve_tiles(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
+    const int dtiles = D >> 6, rt = L.row_tiles;
+    int t = blockIdx.x;
+    const int dt = t % dtiles; t /= dtiles;
+    const int rtile = t % rt;
+    const int bi = t / rt;
+    const _Float16* GHh = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * 64 * npad;
+    const _Float16* GHl = GHh + (size_t)NM * npad;
+    const _Float16* CHh = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * 64;
+    const _Float16* CHl = CHh + (size_t)N * D;
+    const int rows_a = min(64, NM - rtile * 64);
+    const int a = wid >> 1, b = wid & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < npad; k0 += 64) {
+        const int rows_b = min(64, N - k0);
+        stage_tile(GHh + k0, npad, rows_a, T.Ah, tid);
+        stage_tile(GHl + k0, npad, rows_a, T.Al, tid);
+        stage_tile(CHh + (size_t)k0 * D, D, rows_b, T.Bh, tid);
+        stage_tile(CHl + (size_t)k0 * D, D, rows_b, T.Bl, tid);
+        __syncthreads();
+        const int oa = (32 * a + (lane & 31)) * TP + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = mfma3(frag_row(T.Ah + oa + 16 * s), frag_row(T.Al + oa + 16 * s),
+                        frag_tr(T.Bh, TP, 16 * s, 32 * b, lane), frag_tr(T.Bl, TP, 16 * s, 32 * b, lane), acc);
+        __syncthreads();
+    }
+    const float* E = p.E + (size_t)bi * NM * D;
+    float* dE = p.dE + (size_t)bi * NM * D;
+    const float* CHf = p.ws + L.chf + (size_t)bi * N * D;
+    const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
+    const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int d = dt * 64 + 32 * b + l31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = rtile * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (r < NM) {
+            const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)r * 8);  // ra c1e c2s c3
+            const int j = r / M;
+            dE[(size_t)r * D + d] = acc[i] * rs.x + E[(size_t)r * D + d] * rs.y + CHf[(size_t)j * D + d] * rs.z +
+                                    KJ[(size_t)j * D + d];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce: one workgroup per batch, fixed-order sums of the per-row loss / dw / db.
+__global__ __launch_bounds__(256) void ge2e_tiled_reduce(Problem p, TiledWs L) {
+    __shared__ float red[3][256];
+    const int bi = blockIdx.x, tid = threadIdx.x, NM = p.N * p.M;
+    const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
+    float l = 0.f, a = 0.f, c = 0.f;
+    for (int r = tid; r < NM; r += 256) { l += RS[(size_t)r * 8 + 5]; a += RS[(size_t)r * 8 + 6]; c += RS[(size_t)r * 8 + 7]; }
+    red[0][tid] = l; red[1][tid] = a; red[2][tid] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (p.loss) p.loss[bi] = red[0][0];
+        if (p.dw) p.dw[bi] = red[1][0];
+        if (p.db) p.db[bi] = red[2][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+bool tiled_supports(int N, int M, int D) {
+    return N >= 1 && N <= 1024 && M >= 2 && D >= 64 && D <= 1024 && (D % 64) == 0;
+}
+
+TiledWs tiled_layout(int B, int N, int M, int D) {
+    TiledWs L;
+    const size_t NM = (size_t)N * M;
+    L.npad = (N + 63) / 64 * 64;
+    L.row_tiles = (int)((NM + 63) / 64);
+    L.cen_tiles = L.npad / 64;
+    size_t off = 0;  // offsets in floats; fp16 planes take half a float per element
+    auto take = [&](size_t floats) { const size_t o = off; off = align_up(off + floats, 64); return o; };
+    L.ch = take((size_t)B * N * D);          // 2 planes x [N][D] halfs
+    L.eh = take((size_t)B * NM * D);         // 2 planes x [NM][D] halfs
+    L.gh = take((size_t)B * NM * L.npad);    // 2 planes x [NM][npad] halfs
+    L.chf = take((size_t)B * N * D);
+    L.x = take((size_t)B * NM * L.npad);
+    L.gc = take((size_t)B * N * D);
+    L.kj = take((size_t)B * N * D);
+    L.cst = take((size_t)B * N * 4);
+    L.rst = take((size_t)B * NM * 4);
+    L.rs = take((size_t)B * NM * 8);
+    L.total = off;
+    return L;
+}
+
+size_t tiled_workspace_bytes(int B, int N, int M, int D) { return tiled_layout(B, N, M, D).total * sizeof(float); }
+
+hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
+    const TiledWs L = tiled_layout(p.B, p.N, p.M, p.D);
+    const int NM = p.N * p.M;
+    const unsigned spk_blocks = (unsigned)((p.B * p.N + 3) / 4);
+    const unsigned row_blocks = (unsigned)(((size_t)p.B * NM + 3) / 4);
+    hipLaunchKernelGGL(ge2e_tiled_prep, dim3(spk_blocks), dim3(256), 0, stream, p, L);
+    hipLaunchKernelGGL(ge2e_tiled_sim, dim3((unsigned)(p.B * L.row_tiles * L.cen_tiles)), dim3(256), 0, stream, p, L);
+    hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
+    if (p.dE) {
+        hipLaunchKernelGGL(ge2e_tiled_gc, dim3((unsigned)(p.B * L.cen_tiles * (p.D / 64))), dim3(256), 0, stream, p, L);
+        hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
+        hipLaunchKernelGGL(ge2e_tiled_ge, dim3((unsigned)(p.B * L.row_tiles * (p.D / 64))), dim3(256), 0, stream, p, L);
+    }
+    hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
+    return hipGetLastError();
+}
+
+}  // namespace ge2e
