@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws + (size_t)blockIdx.x * wsl.stride, ws_bytes);
     const unsigned offA = (unsigned)(wsl.stash_a * 4), offR = (unsigned)(wsl.stash_rs * 4);
-    const unsigned offDC = (unsigned)(wsl.dcm * 4), offKP = (unsigned)(wsl.dump * 4), offSM = (unsigned)(wsl.sums * 4);
+    const unsigned offKP = (unsigned)(wsl.dump * 4), offSM = (unsigned)(wsl.sums * 4);
 
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
     const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
@@ -467,19 +467,30 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                 }
         }
         __syncthreads();
-        for (int k = wid; k < N; k += NWAVE) {
-            float4 g = zero4(), c = g;
-            if (dact) {
-                g = *reinterpret_cast<const float4*>(GCS + k * P + d4);
-                c = scale4(get_join4(CHh, CHl, k * PH + d4), kSplitInv);
+        {
+            // the complete per-speaker rows KJ_k = dc_k / M + KJP_k replace gC in place: sweep 3 does not
+            // use the e-hat images, so their LDS holds all 64 rows for the epilogue (no workspace trip)
+            float4 kp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kp[u] = bload4(rsW, vrow, offKP + (unsigned)min(wid + NWAVE * u, N - 1) * ROWB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = wid + NWAVE * u;
+                if (k < N) {
+                    float4 g = zero4(), c = g;
+                    if (dact) {
+                        g = *reinterpret_cast<const float4*>(GCS + k * P + d4);
+                        c = scale4(get_join4(CHh, CHl, k * PH + d4), kSplitInv);
+                    }
+                    const float coef = wave_sum(dot4(g, c));
+                    const float rn = CST[k * 4 + 0], kap = CST[k * 4 + 1];
+                    const float f = kap * coef, sc = rn / fM;
+                    if (dact)
+                        *reinterpret_cast<float4*>(GCS + k * P + d4) =
+                            make_float4((g.x - f * c.x) * sc + kp[u].x, (g.y - f * c.y) * sc + kp[u].y,
+                                        (g.z - f * c.z) * sc + kp[u].z, (g.w - f * c.w) * sc + kp[u].w);
+                }
             }
-            const float4 kp = bload4(rsW, vrow, offKP + (unsigned)k * ROWB);
-            const float coef = wave_sum(dot4(g, c));
-            const float rn = CST[k * 4 + 0], kap = CST[k * 4 + 1];
-            const float f = kap * coef, sc = rn / fM;
-            bstore4(rsW, vrow, offDC + (unsigned)k * ROWB,   // the complete per-speaker row KJ_k
-                    make_float4((g.x - f * c.x) * sc + kp.x, (g.y - f * c.y) * sc + kp.y,
-                                (g.z - f * c.z) * sc + kp.z, (g.w - f * c.w) * sc + kp.w));
         }
         __syncthreads();
         GE2E_PROF(5);
@@ -489,13 +500,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         // layout (row 32 kh + 8 g + 4 ps + sub, columns 64 sl + 4 l16) and enter dE with the stored
         // coefficient c1 |e|^-1.  Prefetch group of a tile: those rows, the stashed G images, the
         // row scalars and this wave's speaker row KJ_j (macro, not a lambda: captured arrays go to scratch).
-        float4 a4_0, a4_1, r4, kj_0;
+        float4 a4_0, a4_1, r4;
         float4 ev[4][2];
         const unsigned vep = slice_on ? (unsigned)((32 * kh + sub) * D + 64 * sl + 4 * l16) * 4u : OOB;
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
-        kj_0 = bload4(rsW, vrow, offDC + (unsigned)min(t_ * spt + wid, N - 1) * ROWB);                \
         const unsigned ta_ = offA + (unsigned)t_ * (TR * NC * 4);                                     \
         a4_0 = bload4(rsW, (unsigned)tid * 16u, ta_);                                                 \
         a4_1 = bload4(rsW, (unsigned)tid * 16u, ta_ + TR * NC * 2);                                   \
@@ -557,7 +567,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
             // stashed images: float4 f holds 8 halfs of row f / 8 (512 float4 per image)
             *reinterpret_cast<float4*>(Gh + (tid >> 3) * GP + (tid & 7) * 8) = a4_0;
             *reinterpret_cast<float4*>(Gl + (tid >> 3) * GP + (tid & 7) * 8) = a4_1;
-            if (dact && wid < nspk) *reinterpret_cast<float4*>(KJ + wid * D + d4) = kj_0;
             __syncthreads();
             GE2E_LOAD_TILE3(min(t + 1, ntiles - 1));   // first: vmcnt retires in order, and the next (a) waits on these
             GE2E_RING2_STEP();                         // next batch's rows: 8 summed, 8 requested (HBM latency)
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         const int j = rv ? __float_as_int(rs.w) : j0;
                         const float4 e = ev[g][ps];
                         const float4 cj = get_join4(CHh, CHl, j * PH + col);
-                        const float4 kj = *reinterpret_cast<const float4*>(KJ + (j - j0) * D + col);
+                        const float4 kj = *reinterpret_cast<const float4*>(GCS + j * P + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
                         bstore4<GE2E_AUX_DE>(rsG, rv ? vst : OOB, (unsigned)(r0 + 32 * kh + 8 * g + 4 * ps) * ROWB,
                                 make_float4(acc.x * rs.x + e.x * rs.y + cj.x * rs.z + kj.x, acc.y * rs.x + e.y * rs.y + cj.y * rs.z + kj.y,
