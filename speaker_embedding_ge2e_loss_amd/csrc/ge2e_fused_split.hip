@@ -31,6 +31,9 @@
 #include "ge2e_fused.hpp"
 #include "ge2e_split_gemm.hpp"
 
+#ifndef GE2E_EXP
+#define GE2E_EXP 0   // bit mask of timing experiments (tools/exp_traffic.py); 0 in every shipped build
+#endif
 namespace ge2e {
 
 namespace {
@@ -92,6 +95,24 @@ __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& 
     } else {
         unit_stats(sq, eps_cos, rn, kappa);
     }
+}
+// 4 x 4 transpose inside each quad of lanes: lane p of the quad enters with x[q] = R[q][p] (four
+// registers = four rows, its own column) and leaves with x[k] = R[p][k] (one row, four consecutive
+// columns) -- two DPP butterfly stages, no LDS.
+__device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
+    // every DPP move is executed by ALL lanes before the selects: inside a ?: arm the compiler would
+    // run it under a partial EXEC mask and the disabled source lanes would read as zero
+    const bool even = (lane & 1) == 0, lo = (lane & 2) == 0;
+    const float d0 = dpp_f<DPP_XOR1>(x[0]), d1 = dpp_f<DPP_XOR1>(x[1]);
+    const float d2 = dpp_f<DPP_XOR1>(x[2]), d3 = dpp_f<DPP_XOR1>(x[3]);
+    const float n0 = even ? x[0] : d1, n1 = even ? d0 : x[1];
+    const float n2 = even ? x[2] : d3, n3 = even ? d2 : x[3];
+    const float q0 = dpp_f<DPP_XOR2>(n0), q1 = dpp_f<DPP_XOR2>(n1);
+    const float q2 = dpp_f<DPP_XOR2>(n2), q3 = dpp_f<DPP_XOR2>(n3);
+    x[0] = lo ? n0 : q2;
+    x[1] = lo ? n1 : q3;
+    x[2] = lo ? q0 : n2;
+    x[3] = lo ? q1 : n3;
 }
 // write 4 scaled values as fp16 hi / lo at the same (row, col) of two images
 __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
@@ -167,7 +188,21 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     bool have_sums = false;   // speaker sums of the current batch already sit in the workspace
     for (int bi = blockIdx.x; bi < p.B; bi += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
+#if GE2E_EXP & 8   // timing experiment only: sweep 2 reads ONE batch's rows
+        const __amdgpu_buffer_rsrc_t rsE2s = make_rsrc(p.E, (unsigned)NM * ROWB);
+#else
+        const __amdgpu_buffer_rsrc_t rsE2s = rsE;
+#endif
+#if GE2E_EXP & 2   // timing experiment only (wrong results): sweep 3 re-reads ONE batch's rows, L2-resident
+        const __amdgpu_buffer_rsrc_t rsE3 = make_rsrc(p.E, (unsigned)NM * ROWB);
+#else
+        const __amdgpu_buffer_rsrc_t rsE3 = rsE;
+#endif
+#if GE2E_EXP & 4   // timing experiment only: every workgroup writes batch 0's dE
+        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE : nullptr,
+#else
         const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
+#endif
                                                       want_grad ? (unsigned)NM * ROWB : 0u);
 
         // ================= sweep 1: speaker sums -> unit centroid images =====================
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                     \
             const unsigned vo_ = (8 * wid + 4 * g + sub < nrows_) ? vtile : OOB;            \
             _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                 \
-                v[g][c] = bload4<AUX>(rsE, vo_, tb_ + (unsigned)(4 * g) * ROWB + 256u * c); \
+                v[g][c] = bload4<AUX>(rsE2s, vo_, tb_ + (unsigned)(4 * g) * ROWB + 256u * c); \
         }                                                                                   \
     } while (0)
 
@@ -502,7 +537,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         // row scalars and this wave's speaker row KJ_j (macro, not a lambda: captured arrays go to scratch).
         float4 a4_0, a4_1, r4;
         float4 ev[4][2];
-        const unsigned vep = slice_on ? (unsigned)((32 * kh + sub) * D + 64 * sl + 4 * l16) * 4u : OOB;
+        // raw rows in the epilogue's layout: row 32 kh + 8 g + 4 h + (lane & 3), columns 64 sl + 32 b + 4 (l31 >> 2)
+        const int pq = lane & 3, cq = l31 >> 2;
+        const unsigned vep = slice_on ? (unsigned)((32 * kh + 4 * h + pq) * D + 64 * sl + 4 * cq) * 4u : OOB;
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
@@ -517,15 +554,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         const int nrows_ = min(spt, N - j0_) * M;                                                     \
         const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                              \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                 \
-            _Pragma("unroll") for (int ps = 0; ps < 2; ++ps)                                          \
-                ev[g][ps] = bload4<GE2E_AUX_E3>(rsE, (32 * kh + 8 * g + 4 * ps + sub < nrows_) ? vep : OOB, \
-                                                tb_ + (unsigned)(8 * g + 4 * ps) * ROWB);             \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                             \
+                ev[g][b] = bload4<GE2E_AUX_E3>(rsE3, (32 * kh + 8 * g + 4 * h + pq < nrows_) ? vep : OOB, \
+                                               tb_ + (unsigned)(8 * g) * ROWB + 128u * b);            \
     } while (0)
 
         // the next batch of this workgroup: its rows are summed per speaker underneath this sweep
         const int bnext = bi + gridDim.x;
         const bool has_next = bnext < p.B;
+#if GE2E_EXP & 1   // timing experiment only: the next batch's sums are taken from batch 0's rows
+        const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E,
+#else
         const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E + (size_t)(has_next ? bnext : bi) * NM * D,
+#endif
                                                        has_next ? (unsigned)NM * ROWB : 0u);
         const int nr2 = has_next ? nr_w : 0;
         const unsigned base2 = (unsigned)(jb * M) * ROWB;
@@ -578,43 +619,35 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ge[b][i] = 0.f;
             if (slice_on) gemm_nn_32x64(Gh, Gl, GP, 32 * kh, CHh, CHl, PH, 64 * sl, lane, ge);
-            __syncthreads();  // every wave is done reading the G images
             GE2E_PROF(7);
-            // -- (d) epilogue: accumulator layout (lane = column) -> row layout through this wave's
-            //        8 x 64 staging block (the G images are dead now), then 16-byte stores, 4 rows x
-            //        256 B per wave-instruction:  dE = ra acc + c1e e + rc c-hat_j + KJ_j
+            // -- (d) epilogue straight from the accumulators: a 4 x 4 in-quad transpose gives every lane
+            //        four consecutive columns of ONE row, so the stores are 16 bytes wide (8 rows x 128 B
+            //        per wave-instruction) with no LDS staging and no barrier after the GEMM:
+            //        dE = ra acc + c1e e + rc c-hat_j + KJ_j
             if (slice_on) {
-                float* ST = AT + wid * (8 * APITCH);
-                const int col = 64 * sl + 4 * l16;
-                const unsigned vst = (unsigned)(sub * D + col) * 4u;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {      // four chunks of 8 rows: 32 kh + 8 g + (4 h + q)
+                for (int g = 0; g < 4; ++g) {
+                    const int rl = 32 * kh + 8 * g + 4 * h + pq;
+                    const bool rv = rl < nrows;
+                    const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 4);  // ra c1e rc j
+                    const int j = rv ? __float_as_int(rs.w) : j0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) ST[(4 * h + q) * APITCH + 32 * b + l31] = ge[b][4 * g + q];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        const int rloc = 4 * ps + sub;
-                        const int rl = 32 * kh + 8 * g + rloc;
-                        const bool rv = rl < nrows;
-                        const float4 acc = *reinterpret_cast<const float4*>(ST + rloc * APITCH + 4 * l16);
-                        const float4 rs = *reinterpret_cast<const float4*>(RS + rl * 4);  // ra c1e rc j
-                        const int j = rv ? __float_as_int(rs.w) : j0;
-                        const float4 e = ev[g][ps];
+                    for (int b = 0; b < 2; ++b) {
+                        float x[4] = {ge[b][4 * g], ge[b][4 * g + 1], ge[b][4 * g + 2], ge[b][4 * g + 3]};
+                        quad_transpose4(x, lane);
+                        const int col = 64 * sl + 32 * b + 4 * cq;
+                        const float4 e = ev[g][b];
                         const float4 cj = get_join4(CHh, CHl, j * PH + col);
                         const float4 kj = *reinterpret_cast<const float4*>(GCS + j * P + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
-                        bstore4<GE2E_AUX_DE>(rsG, rv ? vst : OOB, (unsigned)(r0 + 32 * kh + 8 * g + 4 * ps) * ROWB,
-                                make_float4(acc.x * rs.x + e.x * rs.y + cj.x * rs.z + kj.x, acc.y * rs.x + e.y * rs.y + cj.y * rs.z + kj.y,
-                                            acc.z * rs.x + e.z * rs.y + cj.z * rs.z + kj.z, acc.w * rs.x + e.w * rs.y + cj.w * rs.z + kj.w));
+                        bstore4<GE2E_AUX_DE>(rsG, rv ? (unsigned)((4 * h + pq) * D + col) * 4u : OOB,
+                                             (unsigned)(r0 + 32 * kh + 8 * g) * ROWB,
+                                make_float4(x[0] * rs.x + e.x * rs.y + cj.x * rs.z + kj.x, x[1] * rs.x + e.y * rs.y + cj.y * rs.z + kj.y,
+                                            x[2] * rs.x + e.z * rs.y + cj.z * rs.z + kj.z, x[3] * rs.x + e.w * rs.y + cj.w * rs.z + kj.w));
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
+            GE2E_PROF(9);
             GE2E_LOAD_EROWS(min(t + 1, ntiles - 1));   // consumed by the next epilogue; same registers
             __syncthreads();
             GE2E_PROF(8);

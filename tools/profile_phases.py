@@ -24,8 +24,8 @@ import bench  # noqa: E402
 PHASES = {
     "fused_f32": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
                   "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
-    "fused_split": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
-                    "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
+    "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
+                    "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
 
 
