@@ -105,6 +105,18 @@ int ge2e_selftest_split_gemm(const float* A, const float* Bm, const float* G,
 /* x [64] -> out [384]: wave_sum, wave_max, row16_sum, quad_sum, wave_argmax idx, quad_argmax idx. */
 int ge2e_selftest_wave_ops(const float* x, float* out, void* stream);
 
+/* One wave of the team kernel's per-speaker chain on caller data: CH [64][256], R [16][256] (unit rows)
+ * -> XT [64][16] = CH.R^T (16x16x32 tiles), GE [16][256] = XT^T.CH with XT taken straight from the
+ * accumulators, GT = GE stored through the in-quad register transpose. */
+int ge2e_selftest_rows16(const float* CH, const float* R, float* XT, float* GE, float* GT, void* stream);
+/* Team formation (8 workgroups of one XCD) + the L2 hand-off protocol under load: `grid` workgroups
+ * (cooperative launch), `rounds` publish/consume rounds of `payload_f4` float4 per member.
+ * out [16] (device): [0] complete teams, [1] mismatching float4 read back, [2..9] workgroups per XCD,
+ * [10] abort word.  ws: ge2e_selftest_team_bytes(payload_f4) bytes, 256-byte aligned. */
+size_t ge2e_selftest_team_bytes(int payload_f4);
+int ge2e_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds, int payload_f4, unsigned* out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

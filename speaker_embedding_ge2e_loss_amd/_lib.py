@@ -35,6 +35,9 @@ PROTOTYPES = {
     "ge2e_calc_loss": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp]),
     "ge2e_selftest_split_gemm": (C.c_int, [_fp] * 7),
     "ge2e_selftest_wave_ops": (C.c_int, [_fp] * 3),
+    "ge2e_selftest_rows16": (C.c_int, [_fp] * 6),
+    "ge2e_selftest_team_bytes": (C.c_size_t, [C.c_int]),
+    "ge2e_selftest_team": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_centroids": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
 }
 

@@ -151,4 +151,17 @@ int ge2e_selftest_wave_ops(const float* x, float* out, void* stream) {
     return (int)launch_selftest_wave(x, out, (hipStream_t)stream);
 }
 
+int ge2e_selftest_rows16(const float* CH, const float* R, float* XT, float* GE, float* GT, void* stream) {
+    if (!CH || !R || !XT || !GE || !GT) return GE2E_ERR_NULL;
+    return (int)launch_selftest_rows16(CH, R, XT, GE, GT, (hipStream_t)stream);
+}
+
+size_t ge2e_selftest_team_bytes(int payload_f4) { return payload_f4 > 0 ? selftest_team_bytes(payload_f4) : 0; }
+
+int ge2e_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds, int payload_f4, unsigned* out, void* stream) {
+    if (!ws || !out) return GE2E_ERR_NULL;
+    if (rounds < 1 || payload_f4 < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_selftest_team(ws, ws_bytes, grid, rounds, payload_f4, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -74,6 +74,24 @@ constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i inside each row of 1
 #define GE2E_SWAP16(u) __builtin_amdgcn_permlane16_swap((u), (u), false, false)
 #define GE2E_SWAP32(u) __builtin_amdgcn_permlane32_swap((u), (u), false, false)
 
+// 4 x 4 transpose inside each quad of lanes: lane p of the quad enters with x[q] = R[q][p] (four
+// registers = four rows, its own column) and leaves with x[k] = R[p][k] (one row, four consecutive
+// columns) -- two DPP butterfly stages, no LDS.
+__device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
+    // every DPP move is executed by ALL lanes before the selects: inside a ?: arm the compiler would
+    // run it under a partial EXEC mask and the disabled source lanes would read as zero
+    const bool even = (lane & 1) == 0, lo = (lane & 2) == 0;
+    const float d0 = dpp_f<DPP_XOR1>(x[0]), d1 = dpp_f<DPP_XOR1>(x[1]);
+    const float d2 = dpp_f<DPP_XOR1>(x[2]), d3 = dpp_f<DPP_XOR1>(x[3]);
+    const float n0 = even ? x[0] : d1, n1 = even ? d0 : x[1];
+    const float n2 = even ? x[2] : d3, n3 = even ? d2 : x[3];
+    const float q0 = dpp_f<DPP_XOR2>(n0), q1 = dpp_f<DPP_XOR2>(n1);
+    const float q2 = dpp_f<DPP_XOR2>(n2), q3 = dpp_f<DPP_XOR2>(n3);
+    x[0] = lo ? n0 : q2;
+    x[1] = lo ? n1 : q3;
+    x[2] = lo ? q0 : n2;
+    x[3] = lo ? q1 : n3;
+}
 __device__ __forceinline__ float quad_sum(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); return v; }
 __device__ __forceinline__ float quad_max(float v) {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); return v;

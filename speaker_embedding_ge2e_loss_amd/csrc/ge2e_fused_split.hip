@@ -96,24 +96,6 @@ __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& 
         unit_stats(sq, eps_cos, rn, kappa);
     }
 }
-// 4 x 4 transpose inside each quad of lanes: lane p of the quad enters with x[q] = R[q][p] (four
-// registers = four rows, its own column) and leaves with x[k] = R[p][k] (one row, four consecutive
-// columns) -- two DPP butterfly stages, no LDS.
-__device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
-    // every DPP move is executed by ALL lanes before the selects: inside a ?: arm the compiler would
-    // run it under a partial EXEC mask and the disabled source lanes would read as zero
-    const bool even = (lane & 1) == 0, lo = (lane & 2) == 0;
-    const float d0 = dpp_f<DPP_XOR1>(x[0]), d1 = dpp_f<DPP_XOR1>(x[1]);
-    const float d2 = dpp_f<DPP_XOR1>(x[2]), d3 = dpp_f<DPP_XOR1>(x[3]);
-    const float n0 = even ? x[0] : d1, n1 = even ? d0 : x[1];
-    const float n2 = even ? x[2] : d3, n3 = even ? d2 : x[3];
-    const float q0 = dpp_f<DPP_XOR2>(n0), q1 = dpp_f<DPP_XOR2>(n1);
-    const float q2 = dpp_f<DPP_XOR2>(n2), q3 = dpp_f<DPP_XOR2>(n3);
-    x[0] = lo ? n0 : q2;
-    x[1] = lo ? n1 : q3;
-    x[2] = lo ? q0 : n2;
-    x[3] = lo ? q1 : n3;
-}
 // write 4 scaled values as fp16 hi / lo at the same (row, col) of two images
 __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
     h4 hi, lo;

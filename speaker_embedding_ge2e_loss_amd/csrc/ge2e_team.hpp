@@ -1,0 +1,175 @@
+// Building blocks of GE2E_IMPL_TEAM: eight workgroups on eight CUs of ONE XCD share a batch.
+//
+//  * Team formation.  The kernel is launched cooperatively (every workgroup resident, one per CU
+//    because of its LDS footprint).  A workgroup reads the id of the XCD it landed on, takes a
+//    ticket from that XCD's counter and waits until all workgroups of the grid have done so; the
+//    final per-XCD counts then tell every workgroup the same story: tickets 8q..8q+7 of an XCD form
+//    a complete team, leftover workgroups (count not a multiple of 8) exit.  Nothing relies on how
+//    the dispatcher maps workgroup ids to XCDs.
+//  * Hand-offs inside a team go through the XCD's own L2: the producer writes with plain stores,
+//    every storing wave drains its stores (s_waitcnt vmcnt(0) = acknowledged by L2), the workgroup
+//    barrier collects the waves and one lane bumps the team's counter with an agent-scope atomic.
+//    Consumers poll the counter (sc1 load = L2-served) from one lane, pass a workgroup barrier and
+//    read the bytes with sc1 loads only, which bypass the CU's L1 and therefore see the L2 line
+//    the producer wrote.  Both sides sit behind the same L2, so no write-back / invalidate of L2
+//    is needed -- that is the point of keeping a team inside one XCD.
+//  * Every spin is bounded and watches a grid-wide abort word, so the grid always drains.
+#pragma once
+#include "ge2e_common.hpp"
+#include "ge2e_split_gemm.hpp"
+
+namespace ge2e {
+
+constexpr int TEAM = 8;            // workgroups (CUs) per batch
+constexpr int MAX_XCD = 8;
+constexpr unsigned TEAM_SPIN_LIMIT = 1u << 22;
+
+// Control block at the head of the workspace; zeroed by a memset node in front of every launch.
+// Each word that is polled or bumped sits on its own 128-byte line.
+struct TeamCtl {
+    unsigned arrived;   unsigned pad0[31];
+    unsigned abort_;    unsigned pad1[31];
+    unsigned nct;       unsigned pad2[31];              // complete teams (written by workgroup 0, diagnostic)
+    unsigned xcd_count[MAX_XCD][32];                    // one line per XCD
+};
+struct TeamFlags {                                      // per team
+    unsigned c1;        unsigned pad0[31];              // hand-off 1 (unit centroids published)
+    unsigned c2;        unsigned pad1[31];              // hand-off 2 (partial centroid gradients published)
+};
+
+struct TeamId {
+    int team;      // index among the complete teams, -1 = not in one
+    int member;    // 0..7
+    int nct;       // number of complete teams
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & (MAX_XCD - 1);
+}
+__device__ __forceinline__ unsigned ld_poll(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned add_agent(unsigned* p, unsigned v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane: wait until *p >= target.  Returns false when the launch is being aborted.
+__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, TeamCtl* ctl) {
+    for (unsigned it = 0; it < TEAM_SPIN_LIMIT; ++it) {
+        if ((int)(ld_poll(p) - target) >= 0) return true;
+        if ((it & 63) == 63 && ld_poll(&ctl->abort_)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// Called by all threads of the workgroup; `sh` is 4 ints of LDS.  Contains workgroup barriers.
+__device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
+    if (threadIdx.x == 0) {
+        const unsigned x = xcc_id();
+        const unsigned ticket = add_agent(&ctl->xcd_count[x][0], 1u);
+        add_agent(&ctl->arrived, 1u + (ticket & 0u));     // issued after the ticket has been returned
+        int team = -1, member = 0, nct = 0;
+        if (spin_until(&ctl->arrived, gridDim.x, ctl)) {
+            int base = 0;
+            for (int i = 0; i < MAX_XCD; ++i) {
+                const int full = (int)(ld_poll(&ctl->xcd_count[i][0]) / TEAM);
+                if (i == (int)x && (int)ticket < full * TEAM) { team = nct + (int)ticket / TEAM; member = (int)ticket % TEAM; }
+                nct += full;
+            }
+            (void)base;
+        }
+        sh[0] = team; sh[1] = member; sh[2] = nct;
+        if (blockIdx.x == 0) ctl->nct = (unsigned)nct;
+    }
+    __syncthreads();
+    TeamId id;
+    id.team = sh[0]; id.member = sh[1]; id.nct = sh[2];
+    return id;
+}
+
+// Producer side of a hand-off: call from ALL threads after the payload stores were issued.
+__device__ __forceinline__ void team_signal(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) add_agent(counter, 1u);
+}
+// Consumer side: all threads; returns false (uniformly) when aborted.  `sh` = 1 int of LDS.
+__device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned target, TeamCtl* ctl, int* sh) {
+    if (threadIdx.x == 0) sh[0] = spin_until(counter, target, ctl) ? 1 : 0;
+    __syncthreads();
+    const bool ok = sh[0] != 0;
+    __syncthreads();   // sh may be reused right away
+    return ok;
+}
+
+// ---- 16 x 16 x 32 split-fp16 contractions (one wave) ---------------------------------------------
+// v_mfma_f32_16x16x32_f16: A lane (m = lane & 15, kg = lane >> 4) supplies A[m][8 kg .. 8 kg + 7],
+// B lane (n = lane & 15, kg) supplies B[8 kg .. 8 kg + 7][n]; C lane (n = lane & 15, q = lane >> 4)
+// holds C[4 q + i][n] in register i.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma3_16(const h8& ah, const h8& al, const h8& bh, const h8& bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    return acc;
+}
+
+// X[k][r] for 64 centroid slots x 16 rows: acc[t][i] = sum_d CH[16 t + 4 q + i][d] * ROWS[row(l15)][d].
+// Both images row-major with d contiguous; `row_off` = this lane's row offset (in halfs) into the row image.
+template <int KD>
+__device__ __forceinline__ void gemm_x_16rows(const _Float16* CHh, const _Float16* CHl, int pc,
+                                              const _Float16* Rh, const _Float16* Rl, int row_off,
+                                              int lane, f32x4 (&acc)[4]) {
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int off_a = l15 * pc + 8 * kg;
+    const int off_b = row_off + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < KD / 32; ++s) {
+        const h8 bh = frag_row(Rh + off_b + 32 * s), bl = frag_row(Rl + off_b + 32 * s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = mfma3_16(frag_row(CHh + off_a + 16 * t * pc + 32 * s), frag_row(CHl + off_a + 16 * t * pc + 32 * s),
+                              bh, bl, acc[t]);
+    }
+}
+
+// G (this wave's 16 rows x 64 centroid slots, in the accumulator layout of gemm_x_16rows, values
+// already multiplied by kSplitScale) as the A operand of  gE[r][d] = sum_k G[r][k] CH[k][d]:
+// K-step s covers the 32 centroid slots 32 s ..; slot e of lane group kg is k = 32 s + 4 kg + e
+// (e < 4) and 32 s + 16 + 4 kg + e - 4 (e >= 4), i.e. registers g[2 s][0..3], g[2 s + 1][0..3].
+struct GFrag { h8 hi[2], lo[2]; };
+__device__ __forceinline__ GFrag g_to_frag(const f32x4 (&g)[4]) {
+    GFrag f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        h4 h0, l0, h1, l1;
+        split4(make_float4(g[2 * s][0], g[2 * s][1], g[2 * s][2], g[2 * s][3]), h0, l0);
+        split4(make_float4(g[2 * s + 1][0], g[2 * s + 1][1], g[2 * s + 1][2], g[2 * s + 1][3]), h1, l1);
+        f.hi[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f.lo[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    return f;
+}
+// B operand of that contraction for the 16 columns cb.. of the row-major centroid image (K along rows):
+// lane group kg reads block rows 32 s + 4 kg .. + 3 and 32 s + 16 + 4 kg .. + 3 through the transposing load.
+__device__ __forceinline__ h8 frag_tr16(const _Float16* img, int pitch, int s, int cb, int lane) {
+    const int kg = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const _Float16* p = img + (32 * s + 4 * kg + q) * pitch + cb + 4 * pp;
+    const h4 t0 = tr_read4(p);
+    const h4 t1 = tr_read4(p + 16 * pitch);
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// acc[i] += gE[4 q + i][cb + l15]   (one 16 x 16 output tile)
+__device__ __forceinline__ f32x4 gemm_g_ch_tile(const GFrag& g, const _Float16* CHh, const _Float16* CHl, int pc,
+                                                int cb, int lane, f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = mfma3_16(g.hi[s], g.lo[s], frag_tr16(CHh, pc, s, cb, lane), frag_tr16(CHl, pc, s, cb, lane), acc);
+    return acc;
+}
+
+}  // namespace ge2e

@@ -73,3 +73,50 @@ def test_split_fp16_tile_contractions(lib, kind):
         scale = max(1.0, np.abs(ref).max())
         scale = max(scale, float((np.abs(A64).max() * np.abs(B64).max()) * 64)) if kind == "ties" else scale
         assert err <= tol * scale, f"{name}: max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("kind", ["int", "unit"])
+def test_rows16_chain(lib, kind):
+    """16x16x32 tiles: X = CH.R^T, then X (from the accumulators) . CH, plain and through the quad transpose."""
+    rng = np.random.default_rng(3)
+    if kind == "int":
+        CH = rng.integers(-4, 5, (64, 256)).astype(np.float32) / 64
+        R = rng.integers(-4, 5, (16, 256)).astype(np.float32) / 64
+        tol = 1e-7
+    else:
+        CH = rng.standard_normal((64, 256)).astype(np.float32)
+        CH /= np.linalg.norm(CH, axis=1, keepdims=True)
+        R = rng.standard_normal((16, 256)).astype(np.float32)
+        R /= np.linalg.norm(R, axis=1, keepdims=True)
+        tol = 3e-7
+    dev = "cuda:0"
+    d = lambda a: torch.as_tensor(a, device=dev)
+    CHd, Rd = d(CH), d(R)
+    XT = torch.full((64, 16), float("nan"), device=dev)
+    GE = torch.full((16, 256), float("nan"), device=dev)
+    GT = torch.full((16, 256), float("nan"), device=dev)
+    assert lib.ge2e_selftest_rows16(CHd.data_ptr(), Rd.data_ptr(), XT.data_ptr(), GE.data_ptr(), GT.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    xt_ref = CH.astype(np.float64) @ R.astype(np.float64).T
+    assert np.abs(XT.cpu().numpy() - xt_ref).max() <= tol
+    ge_ref = XT.cpu().numpy().astype(np.float64).T @ CH.astype(np.float64)
+    assert np.abs(GE.cpu().numpy() - ge_ref).max() <= 4 * tol
+    assert np.array_equal(GT.cpu().numpy(), GE.cpu().numpy())
+
+
+def test_team_formation_and_l2_handoff(lib):
+    """Every CU gets one workgroup; eight per XCD form a team; payloads handed through L2 arrive intact."""
+    dev = "cuda:0"
+    grid = torch.cuda.get_device_properties(0).multi_processor_count
+    payload, rounds = 512, 200                       # 8 KB per member per round
+    nbytes = lib.ge2e_selftest_team_bytes(payload)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    out = torch.zeros(16, dtype=torch.int32, device=dev)
+    rc = lib.ge2e_selftest_team(ws.data_ptr(), ws.numel(), grid, rounds, payload, out.data_ptr(), None)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert o[10] == 0, "a spin ran into its bound"
+    assert o[2:10].sum() == grid
+    assert o[0] == sum(c // 8 for c in o[2:10]) and o[0] >= 1
+    assert o[1] == 0, f"{o[1]} stale or torn float4 of {o[0] * 8 * 8 * payload * rounds}"
