@@ -47,6 +47,7 @@ extern "C" {
 #define GE2E_IMPL_FUSED_SPLIT 3 /* as FUSED_F32 with fp16 hi+lo split operands on
                                    v_mfma_f32_32x32x16_f16, fp32 accumulate      */
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
+#define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, E resident in LDS: E read once */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */

@@ -1,0 +1,570 @@
+// GE2E_IMPL_TEAM: eight workgroups on eight CUs of one XCD share a batch, E is read from HBM ONCE.
+//
+// The one-workgroup-per-batch kernels (ge2e_fused_*.hip) stream E three times because a batch
+// (N M D fp32 = 655 KB at N=64, M=10, D=256) does not fit one CU.  Split over eight CUs it does:
+// member m of a team keeps the rows of its N/8 speakers resident in LDS (as fp16 hi / lo unit-row
+// images, 84 KB) next to all 64 unit centroids (68 KB), and the three dependent passes of the loss
+// become phases over resident data with two exchanges through the XCD's L2 in between
+// (ge2e_team.hpp: team formation and the hand-off protocol):
+//
+//   P1  wave s owns local speaker s: load its M rows, |e|, e-hat -> ET images; speaker sum -> unit
+//       centroid (scaled 2^8) -> published to the team                                   [hand-off 1]
+//   P2  all 64 published centroids -> CH images (every member, identical bits)
+//   P3  X[k][r] = CH . ET^T for the wave's own 16 (>= M) rows: 16 x 16 x 32 split-fp16 MFMA tiles;
+//       lane (r = lane & 15, q = lane >> 4) ends up with X[16 t + 4 q + i][r]
+//   P4  leave-one-out statistics, softmax / contrast, dL/dS -- in registers: a row's 64 columns sit
+//       in 16 registers of 4 lanes (l, l^16, l^32, l^48)
+//   P5  gE = G . CH with G taken straight from those registers as the A operand (no LDS trip), the
+//       KJ-independent part of dE (ra gE + c1 e-hat + rc c-hat_j) stays in registers (64 VGPRs);
+//       per-speaker row KJP_j = sum_i c3_i e-hat_i + (sum_i c4_i) s_j  (all rows of j are in this wave)
+//   P6  G -> fp16 hi / lo images over the (now dead) centroid images
+//   P7  partial gC[k][d] = sum_{own rows} G[r][k] e-hat[r][d] (32 x 32 x 16 tiles, all 8 waves)
+//       -> published, with the member's loss / dw / db partials                          [hand-off 2]
+//   P8  wave s sums the eight partials of ITS speaker in member order, maps them through the
+//       centroid norm -> KJ_j, adds it to the held rows and stores dE (once).
+//
+// HBM traffic per batch: E read once, dE written once (+ the published rows: 64 KB centroids and
+// 8 x 64 KB partial gradients, which live in L2 and are written through once).
+// Everything a wave does between the two hand-offs concerns its own speaker: the own-speaker column,
+// the leave-one-out centroid, c-hat_j and KJ_j are wave-uniform.
+#include "ge2e_common.hpp"
+#include "ge2e_split_gemm.hpp"
+#include "ge2e_team.hpp"
+
+namespace ge2e {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NC = 64;       // centroid slots
+constexpr int GP = 72;       // G image pitch (halfs)
+constexpr int MAXM = 16;     // rows of one speaker = one 16-row MFMA block
+constexpr unsigned OOB = 0x7FFFFF00u;
+constexpr int AUX_L2 = 16;   // sc1: served by L2, never by this CU's L1 (hand-off reads)
+constexpr int AUX_NT = 2;
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 scale4(const float4& a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int AUX = 0>
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+// whole offset in the VGPR, immediate soffset (ge2e_fused_split.hip: the register-soffset store hazard)
+template <int AUX = 0>
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, AUX);
+}
+__device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
+    if (sq > eps_cos * eps_cos && sq < 1e30f) {
+        float r = __builtin_amdgcn_rsqf(sq);
+        r = r * (1.5f - 0.5f * sq * r * r);
+        rn = r;
+        kappa = 1.0f;
+    } else {
+        unit_stats(sq, eps_cos, rn, kappa);
+    }
+}
+__device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
+    h4 hi, lo;
+    split4(x, hi, lo);
+    *reinterpret_cast<h4*>(hi_img + off) = hi;
+    *reinterpret_cast<h4*>(lo_img + off) = lo;
+}
+__device__ __forceinline__ float4 get_join4(const _Float16* hi_img, const _Float16* lo_img, int off) {
+    return join4(*reinterpret_cast<const h4*>(hi_img + off), *reinterpret_cast<const h4*>(lo_img + off));
+}
+// reductions over the four lanes l, l^16, l^32, l^48 (one row of the X block), result in all four
+__device__ __forceinline__ float col4_sum(float v) {
+    auto a = GE2E_SWAP16(__float_as_uint(v));
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = GE2E_SWAP32(__float_as_uint(v));
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float col4_max(float v) {
+    auto a = GE2E_SWAP16(__float_as_uint(v));
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = GE2E_SWAP32(__float_as_uint(v));
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ void col4_argmax(float& v, int& i) {
+    {
+        auto a = GE2E_SWAP16(__float_as_uint(v));
+        auto b = GE2E_SWAP16((unsigned)i);
+        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
+        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
+        v = v0; i = i0;
+    }
+    {
+        auto a = GE2E_SWAP32(__float_as_uint(v));
+        auto b = GE2E_SWAP32((unsigned)i);
+        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
+        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
+        v = v0; i = i0;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+bool team_supports(int N, int M, int D) {
+    if (!(N >= 1 && N <= NC && M >= 2 && M <= MAXM && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
+    return team_layout(N, M, D).lds_bytes <= 160 * 1024;
+}
+
+TeamWs team_layout(int N, int M, int D) {
+    TeamWs L;
+    L.spm = (N + TEAM - 1) / TEAM;
+    L.rt = (L.spm * M + 15) / 16 * 16;
+    L.chx = 0;                                                // [2][64][D]   published unit centroids * 2^8
+    L.cstx = L.chx + (size_t)2 * NC * D;                      // [2][64][4]   rn, kappa, |s|, |s|^2
+    L.gcx = L.cstx + (size_t)2 * NC * 4;                      // [2][8][64][D] partial centroid gradients
+    L.scx = L.gcx + (size_t)2 * TEAM * NC * D;                // [2][8][4]    loss, dw, db partials
+    L.stride = align_up(L.scx + (size_t)2 * TEAM * 4, 64);
+    L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(TeamFlags), 256);
+    const int PH = D + 8;
+    L.lds_bytes = (size_t)(2 * NC * PH + 2 * L.rt * PH) * 2 + (size_t)(L.rt * 8 + NC * 4 + 32 + 8) * sizeof(float);
+    return L;
+}
+
+static int team_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+// workgroups: one per CU, but no more than eight XCDs' worth of teams for the batches there are
+int team_grid(int B) {
+    const int cus = team_cu_count() / (MAX_XCD * TEAM) * (MAX_XCD * TEAM);
+    const long want = (long)((B + MAX_XCD - 1) / MAX_XCD) * (MAX_XCD * TEAM);
+    return (int)(want < cus ? want : cus);
+}
+size_t team_workspace_bytes(int B, int N, int M, int D) {
+    const TeamWs L = team_layout(N, M, D);
+    return L.head_bytes + (size_t)(team_grid(B) / TEAM) * L.stride * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NCH>  // D = 64 * NCH
+__global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int D = 64 * NCH;
+    constexpr int PH = D + 8;
+    constexpr unsigned ROWB = D * 4;
+    constexpr int NT = 4 * NCH;           // 16-column tiles of a row
+    const int RT = L.rt;
+    _Float16* const CHh = reinterpret_cast<_Float16*>(smem_f);
+    _Float16* const CHl = CHh + NC * PH;
+    _Float16* const ETh = CHl + NC * PH;
+    _Float16* const ETl = ETh + RT * PH;
+    _Float16* const Gh = CHh;                                   // P6..P7: G images over the centroid images
+    _Float16* const Gl = Gh + RT * GP;
+    float* const KJL = reinterpret_cast<float*>(ETh);           // P8: [8][D] fp32 over the ET images
+    float* const RS = reinterpret_cast<float*>(ETl + RT * PH);  // [RT][8]: rne ke ee | ra c1 rc c3 c4
+    float* const CST = RS + RT * 8;                             // [64][4]
+    float* const RED = CST + NC * 4;                            // [32]
+    int* const SH = reinterpret_cast<int*>(RED + 32);           // [8]
+
+    const int N = p.N, M = p.M, NM = N * M;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pq = lane & 3, cq15 = l15 >> 2, cq31 = l31 >> 2;
+    const int d4 = 4 * lane;
+    const bool dact = d4 < D;
+    const int kh = wid >> 2, sl = wid & 3;
+    const bool slice_on = 64 * sl < D;
+
+    TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
+    TeamFlags* const flags = reinterpret_cast<TeamFlags*>(ctl + 1);
+    const TeamId id = team_form(ctl, SH);
+    if (id.nct == 0 && blockIdx.x == 0)   // no eight workgroups share an XCD: fail loudly
+        for (int i = tid; i < p.B; i += 512) p.loss[i] = __builtin_nanf("");
+    if (id.team < 0) return;
+    TeamFlags* const fl = flags + id.team;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
+        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * L.stride * 4, (unsigned)(L.stride * 4));
+
+    const int spm = L.spm;
+    const int j0 = id.member * spm;
+    const int my_spm = max(0, min(spm, N - j0));
+    const int R_my = my_spm * M;
+    const bool has_spk = wid < my_spm;
+    const int j = j0 + wid;                 // this wave's speaker (if has_spk)
+    const int rbase = wid * M;              // its first row in the ET / G images
+
+    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
+    const float fM = (float)M, inv_m1 = 1.0f / (float)(M - 1);
+    const bool contrast = p.variant == 1;
+    const bool want_grad = p.dE != nullptr;
+    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
+
+    // rows of the ET images that never receive an embedding stay zero (they are contracted over in P7)
+    for (int i = tid; i < RT * PH / 8; i += 512) {
+        reinterpret_cast<float4*>(ETh)[i] = zero4();
+        reinterpret_cast<float4*>(ETl)[i] = zero4();
+    }
+    __syncthreads();
+
+    int seq = 0;
+    for (int bi = id.team; bi < p.B; bi += id.nct, ++seq) {
+        const int buf = seq & 1;
+        const unsigned target = (unsigned)(TEAM * (seq + 1));
+        const unsigned offCH = (unsigned)((L.chx + (size_t)buf * NC * D) * 4);
+        const unsigned offCS = (unsigned)((L.cstx + (size_t)buf * NC * 4) * 4);
+        const unsigned offGC = (unsigned)((L.gcx + (size_t)buf * TEAM * NC * D) * 4);
+        const unsigned offSC = (unsigned)((L.scx + (size_t)buf * TEAM * 4) * 4);
+        const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
+        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
+                                                      want_grad ? (unsigned)NM * ROWB : 0u);
+
+        // ===== P1: own rows -> ET images, unit centroid -> team ========================================
+        if (has_spk) {
+            float4 rowv[MAXM];
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i)
+                rowv[i] = bload4(rsE, i < M ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB);
+            float4 s = zero4();
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i) {
+                if (i < M) {
+                    const float4 e = rowv[i];
+                    s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
+                    const float ee = wave_sum(dot4(e, e));
+                    float rne, ke;
+                    unit_stats_fast(ee, eps_cos, rne, ke);
+                    if (dact) put_split4(ETh, ETl, (rbase + i) * PH + d4, scale4(e, rne * kSplitScale));
+                    if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, 0.f);
+                }
+            }
+            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float sq = wave_sum(dot4(c, c));
+            const float ss = wave_sum(dot4(s, s));
+            float rn, kap;
+            unit_stats(sq, eps_cos, rn, kap);
+            bstore4(rsX, vrow, offCH + (unsigned)j * ROWB, scale4(c, rn * kSplitScale));
+            // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
+            bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
+        }
+        team_signal(&fl->c1);                                                             // ---- hand-off 1
+        if (!team_wait(&fl->c1, target, ctl, SH + 4)) return;
+
+        // ===== P2: the 64 published unit centroids -> CH images (slots >= N are zero) =================
+        {
+            float4 cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = wid + 8 * u;
+                cv[u] = bload4<AUX_L2>(rsX, k < N ? vrow : OOB, offCH + (unsigned)min(k, N - 1) * ROWB);
+            }
+            float4 cst = zero4();
+            if (tid < NC) cst = bload4<AUX_L2>(rsX, tid < N ? (unsigned)tid * 16u : OOB, offCS);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dact) put_split4(CHh, CHl, (wid + 8 * u) * PH + d4, cv[u]);
+            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cst;
+        }
+        __syncthreads();
+
+        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        f32x4 g[4];                 // dL/dS of this lane's 16 columns (own column removed), P4 -> P6
+        float4 dEp[NT];             // KJ-independent part of dE: row 4 q + pq, columns 16 t + 4 cq15 ..
+        float4 kjp = zero4();       // speaker row KJP_j, this lane's 4 columns
+        float4 cj_row = zero4();    // c-hat_j, this lane's 4 columns
+        if (has_spk) {
+            // ===== P3: X[k][r] for the wave's own rows ================================================
+            const int irow = min(l15, M - 1);
+            const bool rv = l15 < M;
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+            gemm_x_16rows<D>(CHh, CHl, PH, ETh, ETl, (rbase + irow) * PH, lane, acc);
+
+            // ===== P4: leave-one-out statistics, S, loss, G = dL/dS ===================================
+            const float4 rs0 = *reinterpret_cast<const float4*>(RS + (rbase + irow) * 8);  // rne ke ee
+            const float rne = rv ? rs0.x : 0.f, ke = rs0.y, ee = rs0.z;
+            const float4 cs = *reinterpret_cast<const float4*>(CST + j * 4);                // rn kap |s| |s|^2
+            float xo = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (16 * t + 4 * q + e == j) xo = acc[t][e];
+            xo = col4_sum(xo) * kSplitInv2;                  // c-hat_j . e-hat_r
+            const float rne1 = rv ? rs0.x : 1.0f;
+            const float es = xo * cs.z / rne1;               // e . s_j
+            const float eu = (es - ee) * inv_m1;
+            const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+            float rnu, ku;
+            unit_stats_fast(uu, eps_cos, rnu, ku);
+            const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+            const float sjj = w * (cosd + eps) + bias;
+            float c0[4][4], sv[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 16 * t + 4 * q + e;
+                    c0[t][e] = (k == j) ? cosd : acc[t][e] * kSplitInv2;
+                    sv[t][e] = (k < N) ? w * (c0[t][e] + eps) + bias : -INFINITY;
+                }
+            float per;
+            if (!contrast) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sv[t][e]);
+                mx = fmaxf(col4_max(mx), log_eps);
+                float zoff = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g[t][e] = __expf(sv[t][e] - mx);   // exp(-inf) = 0 for unused slots
+                        if (16 * t + 4 * q + e != j) zoff += g[t][e];
+                    }
+                zoff = col4_sum(zoff) + __expf(log_eps - mx);
+                const float z = zoff + __expf(sjj - mx);
+                per = (mx - sjj) + __logf(z);
+                const float rz = 1.0f / z;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        g[t][e] = (16 * t + 4 * q + e == j) ? -zoff * rz : g[t][e] * rz;   // 1 - p_jj = z_off / z
+            } else {
+                float best = -INFINITY; int besti = 0x7fffffff;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * t + 4 * q + e;
+                        if (k != j && sv[t][e] > best) { best = sv[t][e]; besti = k; }
+                    }
+                col4_argmax(best, besti);
+                const float pos = 1.0f / (1.0f + __expf(-sjj));
+                const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
+                per = 1.0f - pos + neg;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * t + 4 * q + e;
+                        g[t][e] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+                    }
+            }
+            float coef = 0.f, ad = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 16 * t + 4 * q + e;
+                    if (!rv || k >= N) g[t][e] = 0.f;
+                    dw_acc += g[t][e] * (c0[t][e] + eps);
+                    db_acc += g[t][e];
+                    coef += g[t][e] * c0[t][e];     // (dL/d e-hat) . e-hat / w, own-speaker term included
+                    if (k == j) { ad = g[t][e]; g[t][e] = 0.f; }
+                }
+            coef = w * col4_sum(coef);
+            ad = w * col4_sum(ad);                  // dL/dcos on the own-speaker column
+            if (rv && q == 0) {
+                loss_acc += per;
+                if (p.per) p.per[(size_t)bi * NM + j * M + l15] = per;
+            }
+            if (want_grad) {
+                // dE_r = ra acc + c1 e-hat + rc c-hat_j + KJ_j   (ge2e_fused_f32.hip header for the algebra)
+                const float rho = rnu * inv_m1;
+                const float c2 = rho * (ad * rne1 + ad * ku * cosd * rnu * inv_m1);
+                const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
+                const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
+                const float beta = -ad * rnu * ku * cosd * rho;
+                if (rv && q == 0) {
+                    float* r8 = RS + (rbase + l15) * 8;
+                    r8[3] = rne * (w * kSplitInv2);           // of the gE accumulator (carries 2^16)
+                    r8[4] = c1 * kSplitInv;                   // of the e-hat image value (carries 2^8)
+                    r8[5] = c2 * cs.z * kSplitInv;            // of the c-hat_j image value
+                    r8[6] = alpha * inv_m1 * kSplitInv;       // c3: of e-hat_i in the speaker row KJP
+                    r8[7] = beta * inv_m1;                    // c4: of s_j
+                }
+                // ===== P5: gE = G . CH from registers; the part of dE that does not need KJ ==========
+                f32x4 gs[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gs[t][e] = g[t][e] * kSplitScale;
+                const GFrag gf = g_to_frag(gs);
+                const int ir = 4 * q + pq;                    // the row this lane holds after the transpose
+                const bool irv = ir < M;
+                const int irc = min(ir, M - 1);
+                const float* r8 = RS + (rbase + irc) * 8;
+                const float ra = r8[3], c1i = r8[4], rci = r8[5];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    o = gemm_g_ch_tile(gf, CHh, CHl, PH, 16 * t, lane, o);
+                    float x[4] = {o[0], o[1], o[2], o[3]};
+                    quad_transpose4(x, lane);
+                    const int col = 16 * t + 4 * cq15;
+                    const float4 e4 = get_join4(ETh, ETl, (rbase + irc) * PH + col);
+                    const float4 c4 = get_join4(CHh, CHl, j * PH + col);
+                    dEp[t] = irv ? make_float4(x[0] * ra + e4.x * c1i + c4.x * rci, x[1] * ra + e4.y * c1i + c4.y * rci,
+                                               x[2] * ra + e4.z * c1i + c4.z * rci, x[3] * ra + e4.w * c1i + c4.w * rci)
+                                 : zero4();
+                }
+                // speaker row KJP_j (this lane's 4 columns)
+                float bsum = 0.f;
+                if (dact) cj_row = scale4(get_join4(CHh, CHl, j * PH + d4), kSplitInv);
+                for (int i = 0; i < M; ++i) {
+                    const float c3 = RS[(rbase + i) * 8 + 6];
+                    bsum += RS[(rbase + i) * 8 + 7];
+                    if (dact) {
+                        const float4 e = get_join4(ETh, ETl, (rbase + i) * PH + d4);
+                        kjp.x += c3 * e.x; kjp.y += c3 * e.y; kjp.z += c3 * e.z; kjp.w += c3 * e.w;
+                    }
+                }
+                const float bs = bsum * cs.z;
+                kjp.x += bs * cj_row.x; kjp.y += bs * cj_row.y; kjp.z += bs * cj_row.z; kjp.w += bs * cj_row.w;
+            }
+        }
+
+        // ---- member scalars: fixed-order reduction over the 8 waves ----------------------------------
+        loss_acc = wave_sum(loss_acc);
+        dw_acc = wave_sum(dw_acc);
+        db_acc = wave_sum(db_acc);
+        if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
+        __syncthreads();                                   // also: every wave is done with the CH images
+        if (tid == 0) {
+            float l = 0.f, a = 0.f, c = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
+            bstore4(rsX, 0u, offSC + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
+        }
+
+        f32x16 gc[2];
+        if (want_grad) {
+            // ===== P6: G images (fp16 hi / lo, row-major [row][slot]) over the centroid images ========
+            if (has_spk && l15 < M) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    put_split4(Gh, Gl, (rbase + l15) * GP + 16 * t + 4 * q,
+                               make_float4(g[t][0] * kSplitScale, g[t][1] * kSplitScale, g[t][2] * kSplitScale, g[t][3] * kSplitScale));
+            }
+            for (int i = tid; i < (RT - R_my) * (GP / 8); i += 512) {    // rows without an embedding
+                const int r = R_my + i / (GP / 8), c8 = (i % (GP / 8)) * 8;
+                *reinterpret_cast<float4*>(Gh + r * GP + c8) = zero4();
+                *reinterpret_cast<float4*>(Gl + r * GP + c8) = zero4();
+            }
+            __syncthreads();
+            // ===== P7: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ==
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
+            if (slice_on) {
+                for (int s = 0; s < RT / 16; ++s) {
+                    const h8 ah = frag_tr(Gh, GP, 16 * s, 32 * kh, lane), al = frag_tr(Gl, GP, 16 * s, 32 * kh, lane);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        gc[b] = mfma3(ah, al, frag_tr(ETh, PH, 16 * s, 64 * sl + 32 * b, lane),
+                                      frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lane), gc[b]);
+                }
+                const float sc = w * kSplitInv2;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int k = 32 * kh + 8 * g4 + 4 * h + pq;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float x[4] = {gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]};
+                        quad_transpose4(x, lane);
+                        const int col = 64 * sl + 32 * b + 4 * cq31;
+                        bstore4(rsX, k < N ? (unsigned)(k * D + col) * 4u : OOB, offGC + (unsigned)id.member * (NC * ROWB),
+                                make_float4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc));
+                    }
+                }
+            }
+        }
+        team_signal(&fl->c2);                                                             // ---- hand-off 2
+        if (!team_wait(&fl->c2, target, ctl, SH + 4)) return;
+
+        // ===== P8: batch scalars; own speaker's gC -> KJ_j; dE = held part + KJ_j ======================
+        if (id.member == 0 && tid == 0) {
+            float l = 0.f, a = 0.f, c = 0.f;
+            for (int m = 0; m < TEAM; ++m) {
+                const float4 v = bload4<AUX_L2>(rsX, 0u, offSC + (unsigned)m * 16u);
+                l += v.x; a += v.y; c += v.z;
+            }
+            if (p.loss) p.loss[bi] = l;
+            if (p.dw) p.dw[bi] = a;
+            if (p.db) p.db[bi] = c;
+        }
+        if (want_grad && has_spk) {
+            float4 part[TEAM];
+#pragma unroll
+            for (int m = 0; m < TEAM; ++m) part[m] = bload4<AUX_L2>(rsX, vrow, offGC + (unsigned)(m * NC + j) * ROWB);
+            float4 gsum = part[0];
+#pragma unroll
+            for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+            const float coefc = wave_sum(dot4(gsum, cj_row));
+            const float rn = CST[j * 4 + 0], kap = CST[j * 4 + 1];
+            const float f = kap * coefc, sc = rn / fM;
+            if (dact)
+                *reinterpret_cast<float4*>(KJL + wid * D + d4) =
+                    make_float4((gsum.x - f * cj_row.x) * sc + kjp.x, (gsum.y - f * cj_row.y) * sc + kjp.y,
+                                (gsum.z - f * cj_row.z) * sc + kjp.z, (gsum.w - f * cj_row.w) * sc + kjp.w);
+            const int ir = 4 * q + pq;
+            const unsigned vo = ir < M ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 kj = *reinterpret_cast<const float4*>(KJL + wid * D + 16 * t + 4 * cq15);
+                bstore4<AUX_NT>(rsG, vo, 64u * t,
+                                make_float4(dEp[t].x + kj.x, dEp[t].y + kj.y, dEp[t].z + kj.z, dEp[t].w + kj.w));
+            }
+        }
+        __syncthreads();   // KJL lives over the ET images, which the next batch's P1 rewrites
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+static hipError_t launch_nch(Problem& p, TeamWs& L, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH>);
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
+    if (err != hipSuccess) return err;
+    err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
+    if (err != hipSuccess) return err;
+    void* args[] = {&p, &L};
+    return hipLaunchCooperativeKernel(fn, dim3(team_grid(p.B)), dim3(512), args, L.lds_bytes, stream);
+}
+
+hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
+    Problem p = p_in;
+    TeamWs L = team_layout(p.N, p.M, p.D);
+    switch (p.D / 64) {
+        case 1: return launch_nch<1>(p, L, stream);
+        case 2: return launch_nch<2>(p, L, stream);
+        case 3: return launch_nch<3>(p, L, stream);
+        default: return launch_nch<4>(p, L, stream);
+    }
+}
+
+}  // namespace ge2e

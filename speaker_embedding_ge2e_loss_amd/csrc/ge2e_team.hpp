@@ -70,16 +70,15 @@ __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
     if (threadIdx.x == 0) {
         const unsigned x = xcc_id();
         const unsigned ticket = add_agent(&ctl->xcd_count[x][0], 1u);
-        add_agent(&ctl->arrived, 1u + (ticket & 0u));     // issued after the ticket has been returned
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket add has been performed before "arrived" moves
+        add_agent(&ctl->arrived, 1u);
         int team = -1, member = 0, nct = 0;
         if (spin_until(&ctl->arrived, gridDim.x, ctl)) {
-            int base = 0;
             for (int i = 0; i < MAX_XCD; ++i) {
                 const int full = (int)(ld_poll(&ctl->xcd_count[i][0]) / TEAM);
                 if (i == (int)x && (int)ticket < full * TEAM) { team = nct + (int)ticket / TEAM; member = (int)ticket % TEAM; }
                 nct += full;
             }
-            (void)base;
         }
         sh[0] = team; sh[1] = member; sh[2] = nct;
         if (blockIdx.x == 0) ctl->nct = (unsigned)nct;
@@ -171,5 +170,19 @@ __device__ __forceinline__ f32x4 gemm_g_ch_tile(const GFrag& g, const _Float16* 
         acc = mfma3_16(g.hi[s], g.lo[s], frag_tr16(CHh, pc, s, cb, lane), frag_tr16(CHl, pc, s, cb, lane), acc);
     return acc;
 }
+
+// ---- GE2E_IMPL_TEAM (ge2e_team.hip) ---------------------------------------------------------------
+struct TeamWs {
+    int spm;            // speakers per member = ceil(N / 8)
+    int rt;             // rows of a member's images: spm * M rounded up to 16
+    size_t chx, cstx, gcx, scx, stride;   // per-team exchange area (offsets / size in floats)
+    size_t head_bytes;  // TeamCtl + TeamFlags[64] at the head of the workspace
+    size_t lds_bytes;
+};
+bool team_supports(int N, int M, int D);
+TeamWs team_layout(int N, int M, int D);
+int team_grid(int B);
+size_t team_workspace_bytes(int B, int N, int M, int D);
+hipError_t launch_team(const Problem& p, hipStream_t stream);
 
 }  // namespace ge2e

@@ -19,6 +19,7 @@ TOL = {  # impl -> (loss rtol, dE rel-fro / relative max-abs, dw rtol, cos atol)
     "fused_f32": (5e-6, 1e-5, 2e-5, 2e-6),
     "fused_split": (2e-5, 2e-5, 5e-5, 5e-6),
     "tiled": (2e-5, 2e-5, 5e-5, 5e-6),
+    "team": (2e-5, 2e-5, 5e-5, 5e-6),
     "auto": (1e-4, 1e-4, 1e-4, 1e-5),
 }
 
@@ -33,7 +34,7 @@ def GF():
 
 def impls_for(GF, B, N, M, D, variant="softmax"):
     out = []
-    for name in ("generic", "fused_f32", "fused_split", "tiled"):
+    for name in ("generic", "fused_f32", "fused_split", "tiled", "team"):
         try:
             GF.resolve_impl(B, N, M, D, variant, name)
             out.append(name)
