@@ -21,10 +21,15 @@ unsigned long long* g_prof = nullptr;  // diagnostic build only
 
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
+// AUTO: few batches -> a team of eight CUs per batch (2x lower latency than one CU per batch; with B <=
+// kTeamMaxB every team still has at most two batches); many batches -> one workgroup per batch.
+constexpr int kTeamMaxB = 64;
+
 int resolve(int B, int N, int M, int D, int variant, int impl) {
-    (void)B; (void)variant;
+    (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
+            if (B <= kTeamMaxB && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;

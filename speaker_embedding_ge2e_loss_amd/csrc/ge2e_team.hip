@@ -159,7 +159,7 @@ size_t team_workspace_bytes(int B, int N, int M, int D) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NCH>  // D = 64 * NCH
+template <int NCH, int MR>  // D = 64 * NCH; MR >= M rows of a speaker are held in registers between batches
 __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     _Float16* const ETl = ETh + RT * PH;
     _Float16* const Gh = CHh;                                   // P6..P7: G images over the centroid images
     _Float16* const Gl = Gh + RT * GP;
-    float* const KJL = reinterpret_cast<float*>(ETh);           // P8: [8][D] fp32 over the ET images
+    float* const KJL = reinterpret_cast<float*>(CHh);           // P8: [8][D] fp32 over the (dead) G images
     float* const RS = reinterpret_cast<float*>(ETl + RT * PH);  // [RT][8]: rne ke ee | ra c1 rc c3 c4
     float* const CST = RS + RT * 8;                             // [64][4]
     float* const RED = CST + NC * 4;                            // [32]
@@ -223,6 +223,29 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     }
     __syncthreads();
 
+    // Software pipeline over the team's batches (VMEM retires in issue order, so the order of issue is the
+    // schedule): the rows of the NEXT batch are requested and the finished dE rows of the PREVIOUS batch are
+    // stored right after this batch's centroid hand-off reads were issued; both drain underneath the
+    // LDS / MFMA phases P2..P6, and the publishing waits of hand-off 2 find them long done.
+    float4 rowv[MR];            // this wave's rows of the batch about to start
+    float4 dEp[NT];             // dE of the wave's rows: row 4 q + pq, columns 16 t + 4 cq15 ..  (P5 -> next batch)
+#define GE2E_TEAM_LOAD_ROWS(BI)                                                                          \
+    do {                                                                                                 \
+        const bool on_ = has_spk && (BI) < p.B;                                                          \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
+            rowv[i] = bload4(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+    } while (0)
+#define GE2E_TEAM_STORE_DE(BI)                                                                           \
+    do {                                                                                                 \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.dE + (size_t)(BI) * NM * D, (unsigned)NM * ROWB); \
+        const int ir_ = 4 * q + pq;                                                                      \
+        const unsigned vo_ = ir_ < M ? (unsigned)((j * M + ir_) * D + 4 * cq15) * 4u : OOB;              \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) bstore4<AUX_NT>(rs_, vo_, 64u * t, dEp[t]);       \
+    } while (0)
+
+    GE2E_PROF_DECL(11)
+    GE2E_TEAM_LOAD_ROWS(id.team);
     int seq = 0;
     for (int bi = id.team; bi < p.B; bi += id.nct, ++seq) {
         const int buf = seq & 1;
@@ -231,19 +254,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         const unsigned offCS = (unsigned)((L.cstx + (size_t)buf * NC * 4) * 4);
         const unsigned offGC = (unsigned)((L.gcx + (size_t)buf * TEAM * NC * D) * 4);
         const unsigned offSC = (unsigned)((L.scx + (size_t)buf * TEAM * 4) * 4);
-        const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
-        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
-                                                      want_grad ? (unsigned)NM * ROWB : 0u);
 
         // ===== P1: own rows -> ET images, unit centroid -> team ========================================
         if (has_spk) {
-            float4 rowv[MAXM];
-#pragma unroll
-            for (int i = 0; i < MAXM; ++i)
-                rowv[i] = bload4(rsE, i < M ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB);
             float4 s = zero4();
 #pragma unroll
-            for (int i = 0; i < MAXM; ++i) {
+            for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float4 e = rowv[i];
                     s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
@@ -264,7 +280,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
         }
         team_signal(&fl->c1);                                                             // ---- hand-off 1
+        GE2E_PROF(0);
         if (!team_wait(&fl->c1, target, ctl, SH + 4)) return;
+        GE2E_PROF(1);
 
         // ===== P2: the 64 published unit centroids -> CH images (slots >= N are zero) =================
         {
@@ -276,16 +294,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             }
             float4 cst = zero4();
             if (tid < NC) cst = bload4<AUX_L2>(rsX, tid < N ? (unsigned)tid * 16u : OOB, offCS);
+            // behind the hand-off reads in the memory pipe: last batch's dE rows out, next batch's rows in
+            if (want_grad && has_spk && seq > 0) GE2E_TEAM_STORE_DE(bi - id.nct);
+            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (dact) put_split4(CHh, CHl, (wid + 8 * u) * PH + d4, cv[u]);
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cst;
         }
         __syncthreads();
+        GE2E_PROF(2);
 
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
         f32x4 g[4];                 // dL/dS of this lane's 16 columns (own column removed), P4 -> P6
-        float4 dEp[NT];             // KJ-independent part of dE: row 4 q + pq, columns 16 t + 4 cq15 ..
         float4 kjp = zero4();       // speaker row KJP_j, this lane's 4 columns
         float4 cj_row = zero4();    // c-hat_j, this lane's 4 columns
         if (has_spk) {
@@ -298,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
             gemm_x_16rows<D>(CHh, CHl, PH, ETh, ETl, (rbase + irow) * PH, lane, acc);
+            GE2E_PROF(3);
 
             // ===== P4: leave-one-out statistics, S, loss, G = dL/dS ===================================
             const float4 rs0 = *reinterpret_cast<const float4*>(RS + (rbase + irow) * 8);  // rne ke ee
@@ -387,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 }
             coef = w * col4_sum(coef);
             ad = w * col4_sum(ad);                  // dL/dcos on the own-speaker column
+            GE2E_PROF(4);
             if (rv && q == 0) {
                 loss_acc += per;
                 if (p.per) p.per[(size_t)bi * NM + j * M + l15] = per;
@@ -453,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         db_acc = wave_sum(db_acc);
         if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
         __syncthreads();                                   // also: every wave is done with the CH images
+        GE2E_PROF(5);
         if (tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
@@ -475,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 *reinterpret_cast<float4*>(Gl + r * GP + c8) = zero4();
             }
             __syncthreads();
+            GE2E_PROF(6);
             // ===== P7: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ==
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -504,7 +529,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             }
         }
         team_signal(&fl->c2);                                                             // ---- hand-off 2
+        GE2E_PROF(7);
         if (!team_wait(&fl->c2, target, ctl, SH + 4)) return;
+        GE2E_PROF(8);
 
         // ===== P8: batch scalars; own speaker's gC -> KJ_j; dE = held part + KJ_j ======================
         if (id.member == 0 && tid == 0) {
@@ -531,23 +558,22 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 *reinterpret_cast<float4*>(KJL + wid * D + d4) =
                     make_float4((gsum.x - f * cj_row.x) * sc + kjp.x, (gsum.y - f * cj_row.y) * sc + kjp.y,
                                 (gsum.z - f * cj_row.z) * sc + kjp.z, (gsum.w - f * cj_row.w) * sc + kjp.w);
-            const int ir = 4 * q + pq;
-            const unsigned vo = ir < M ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; ++t) {      // complete rows stay in registers until the next batch's hand-off 1
                 const float4 kj = *reinterpret_cast<const float4*>(KJL + wid * D + 16 * t + 4 * cq15);
-                bstore4<AUX_NT>(rsG, vo, 64u * t,
-                                make_float4(dEp[t].x + kj.x, dEp[t].y + kj.y, dEp[t].z + kj.z, dEp[t].w + kj.w));
+                dEp[t].x += kj.x; dEp[t].y += kj.y; dEp[t].z += kj.z; dEp[t].w += kj.w;
             }
         }
-        __syncthreads();   // KJL lives over the ET images, which the next batch's P1 rewrites
+        GE2E_PROF(9);
     }
+    if (want_grad && has_spk && seq > 0) GE2E_TEAM_STORE_DE(id.team + (seq - 1) * id.nct);
+    GE2E_PROF_FLUSH(11)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, int MR>
 static hipError_t launch_nch(Problem& p, TeamWs& L, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH>);
+    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR>);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
@@ -559,11 +585,19 @@ static hipError_t launch_nch(Problem& p, TeamWs& L, hipStream_t stream) {
 hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem p = p_in;
     TeamWs L = team_layout(p.N, p.M, p.D);
+    if (p.M <= 10) {
+        switch (p.D / 64) {
+            case 1: return launch_nch<1, 10>(p, L, stream);
+            case 2: return launch_nch<2, 10>(p, L, stream);
+            case 3: return launch_nch<3, 10>(p, L, stream);
+            default: return launch_nch<4, 10>(p, L, stream);
+        }
+    }
     switch (p.D / 64) {
-        case 1: return launch_nch<1>(p, L, stream);
-        case 2: return launch_nch<2>(p, L, stream);
-        case 3: return launch_nch<3>(p, L, stream);
-        default: return launch_nch<4>(p, L, stream);
+        case 1: return launch_nch<1, MAXM>(p, L, stream);
+        case 2: return launch_nch<2, MAXM>(p, L, stream);
+        case 3: return launch_nch<3, MAXM>(p, L, stream);
+        default: return launch_nch<4, MAXM>(p, L, stream);
     }
 }
 

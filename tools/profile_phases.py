@@ -24,6 +24,8 @@ import bench  # noqa: E402
 PHASES = {
     "fused_f32": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
                   "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
+    "team": ["P1 rows+publish+signal", "wait 1", "P2 centroids->LDS", "P3 gemm X", "P4 softmax", "P5 gemm gE + part dE + KJP",
+             "P6 G images", "P7 gemm gC + publish + signal", "wait 2", "P8 reduce + dE store"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -82,7 +84,7 @@ def main():
           f"{tot:.0f} cycles per batch per workgroup")
     for i, n in enumerate(names):
         if cyc[i] > 0:
-            print(f"  {n:18s} {cyc[i]:10.0f} cyc  {100 * cyc[i] / tot:5.1f} %")
+            print(f"  {n:34s} {cyc[i]:10.0f} cyc  {100 * cyc[i] / tot:5.1f} %")
 
 
 if __name__ == "__main__":
