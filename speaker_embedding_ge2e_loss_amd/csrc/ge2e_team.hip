@@ -173,7 +173,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     _Float16* const ETl = ETh + RT * PH;
     _Float16* const Gh = CHh;                                   // P6..P7: G images over the centroid images
     _Float16* const Gl = Gh + RT * GP;
-    float* const KJL = reinterpret_cast<float*>(CHh);           // P8: [8][D] fp32 over the (dead) G images
+    float* const KJL = reinterpret_cast<float*>(CHh);           // P8: KJ_j rows [8][D] fp32 over the (dead) G images
+    float* const CJL = KJL + 8 * D;                             //     c-hat_j rows [8][D] fp32
     float* const RS = reinterpret_cast<float*>(ETl + RT * PH);  // [RT][8]: rne ke ee | ra c1 rc c3 c4
     float* const CST = RS + RT * 8;                             // [64][4]
     float* const RED = CST + NC * 4;                            // [32]
@@ -223,12 +224,25 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     }
     __syncthreads();
 
-    // Software pipeline over the team's batches (VMEM retires in issue order, so the order of issue is the
-    // schedule): the rows of the NEXT batch are requested and the finished dE rows of the PREVIOUS batch are
-    // stored right after this batch's centroid hand-off reads were issued; both drain underneath the
-    // LDS / MFMA phases P2..P6, and the publishing waits of hand-off 2 find them long done.
+    // Software pipeline over the team's batches.  VMEM retires in issue order and a hand-off costs a store
+    // drain plus a round trip, so the loop is rotated: an iteration starts batch `cur` (P1) BEFORE it finishes
+    // batch `prev` (P8), publishes both with ONE drain + barrier, and every wait sits behind work:
+    //
+    //   P1(cur)            rows (requested one iteration ago) -> ET images, centroid -> team
+    //   drain, barrier     signal hand-off 2 of prev (its gC partials were stored at the end of the last
+    //                      iteration) and hand-off 1 of cur
+    //   wait 2(prev), P8   gC partials of my speaker -> KJ_j -> the held dE rows of prev are complete
+    //   wait 1(cur), P2    centroids -> CH images
+    //   P3                 X; every K-step also stores two finished tiles of prev's dE (they trickle out under
+    //                      an LDS / MFMA-bound loop instead of blocking a phase, and free their registers)
+    //   P4 P5              softmax, gE -> the held part of cur's dE; then the rows of the NEXT batch are requested
+    //   P6 P7              G images, partial gC -> team (stores only; drained at the top of the next iteration)
     float4 rowv[MR];            // this wave's rows of the batch about to start
-    float4 dEp[NT];             // dE of the wave's rows: row 4 q + pq, columns 16 t + 4 cq15 ..  (P5 -> next batch)
+    float4 dEp[NT];             // dE of the wave's rows: row 4 q + pq, columns 16 t + 4 cq15 ..  (P5 .. next P5)
+    float4 kjp = zero4();       // speaker row KJP_j of prev, this lane's 4 columns (P5 -> P8)
+    float4 cj_row = zero4();    // c-hat_j of prev, this lane's 4 columns
+    float rcs = 0.f;            // coefficient of c-hat_j in this lane's row of prev
+    float rn_j = 0.f, kap_j = 0.f;
 #define GE2E_TEAM_LOAD_ROWS(BI)                                                                          \
     do {                                                                                                 \
         const bool on_ = has_spk && (BI) < p.B;                                                          \
@@ -236,27 +250,29 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
             rowv[i] = bload4(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
     } while (0)
-#define GE2E_TEAM_STORE_DE(BI)                                                                           \
-    do {                                                                                                 \
-        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.dE + (size_t)(BI) * NM * D, (unsigned)NM * ROWB); \
-        const int ir_ = 4 * q + pq;                                                                      \
-        const unsigned vo_ = ir_ < M ? (unsigned)((j * M + ir_) * D + 4 * cq15) * 4u : OOB;              \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) bstore4<AUX_NT>(rs_, vo_, 64u * t, dEp[t]);       \
-    } while (0)
+    const int ir = 4 * q + pq;                                  // the row this lane holds in the tile layout
+    const bool irv = ir < M;
+    const int irc = min(ir, M - 1);
+    const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;
 
-    GE2E_PROF_DECL(11)
+    GE2E_PROF_DECL(13)
     GE2E_TEAM_LOAD_ROWS(id.team);
-    int seq = 0;
-    for (int bi = id.team; bi < p.B; bi += id.nct, ++seq) {
-        const int buf = seq & 1;
-        const unsigned target = (unsigned)(TEAM * (seq + 1));
+    for (int seq = 0;; ++seq) {
+        const int bi = id.team + seq * id.nct;          // batch started in this iteration
+        const bool have_cur = bi < p.B, have_prev = seq > 0;
+        if (!have_cur && !have_prev) break;
+        const int buf = seq & 1, pbuf = buf ^ 1;
         const unsigned offCH = (unsigned)((L.chx + (size_t)buf * NC * D) * 4);
         const unsigned offCS = (unsigned)((L.cstx + (size_t)buf * NC * 4) * 4);
         const unsigned offGC = (unsigned)((L.gcx + (size_t)buf * TEAM * NC * D) * 4);
         const unsigned offSC = (unsigned)((L.scx + (size_t)buf * TEAM * 4) * 4);
+        const unsigned offGCp = (unsigned)((L.gcx + (size_t)pbuf * TEAM * NC * D) * 4);
+        const unsigned offSCp = (unsigned)((L.scx + (size_t)pbuf * TEAM * 4) * 4);
+        const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
+                                                       want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
 
-        // ===== P1: own rows -> ET images, unit centroid -> team ========================================
-        if (has_spk) {
+        // ===== P1(cur): own rows -> ET images, unit centroid -> team ===================================
+        if (has_spk && have_cur) {
             float4 s = zero4();
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
@@ -279,12 +295,65 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
             bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
         }
-        team_signal(&fl->c1);                                                             // ---- hand-off 1
+        // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (have_prev) add_agent(&fl->c2, 1u);
+            if (have_cur) add_agent(&fl->c1, 1u);
+        }
         GE2E_PROF(0);
-        if (!team_wait(&fl->c1, target, ctl, SH + 4)) return;
-        GE2E_PROF(1);
 
-        // ===== P2: the 64 published unit centroids -> CH images (slots >= N are zero) =================
+        // ===== P8(prev): batch scalars; own speaker's gC -> KJ_j; the held rows of dE become complete ==
+        if (have_prev) {
+            if (!team_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4)) return;
+            GE2E_PROF(8);
+            if (id.member == 0 && tid == 0) {
+                float l = 0.f, a = 0.f, c = 0.f;
+                for (int m = 0; m < TEAM; ++m) {
+                    const float4 v = bload4<AUX_L2>(rsX, 0u, offSCp + (unsigned)m * 16u);
+                    l += v.x; a += v.y; c += v.z;
+                }
+                if (p.loss) p.loss[bi - id.nct] = l;
+                if (p.dw) p.dw[bi - id.nct] = a;
+                if (p.db) p.db[bi - id.nct] = c;
+            }
+            if (want_grad && has_spk) {
+                float4 part[TEAM];
+#pragma unroll
+                for (int m = 0; m < TEAM; ++m) part[m] = bload4<AUX_L2>(rsX, vrow, offGCp + (unsigned)(m * NC + j) * ROWB);
+                float4 gsum = part[0];
+#pragma unroll
+                for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+                const float coefc = wave_sum(dot4(gsum, cj_row));
+                const float f = kap_j * coefc, sc = rn_j / fM;
+                if (dact) {
+                    *reinterpret_cast<float4*>(KJL + wid * D + d4) =
+                        make_float4((gsum.x - f * cj_row.x) * sc + kjp.x, (gsum.y - f * cj_row.y) * sc + kjp.y,
+                                    (gsum.z - f * cj_row.z) * sc + kjp.z, (gsum.w - f * cj_row.w) * sc + kjp.w);
+                    *reinterpret_cast<float4*>(CJL + wid * D + d4) = cj_row;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {      // dE_r = held part + rc c-hat_j + KJ_j
+                    const float4 kj = *reinterpret_cast<const float4*>(KJL + wid * D + 16 * t + 4 * cq15);
+                    const float4 cj = *reinterpret_cast<const float4*>(CJL + wid * D + 16 * t + 4 * cq15);
+                    dEp[t].x += kj.x + rcs * cj.x; dEp[t].y += kj.y + rcs * cj.y;
+                    dEp[t].z += kj.z + rcs * cj.z; dEp[t].w += kj.w + rcs * cj.w;
+                }
+            }
+            GE2E_PROF(9);
+        }
+        if (!have_cur) {   // drain: the last batch's rows go out in one piece
+            if (want_grad && has_spk) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bstore4<AUX_NT>(rsGp, vo_de, 64u * t, dEp[t]);
+            }
+            break;
+        }
+
+        // ===== P2(cur): the 64 published unit centroids -> CH images (slots >= N are zero) ==============
+        if (!team_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4)) return;
+        GE2E_PROF(1);
         {
             float4 cv[8];
 #pragma unroll
@@ -294,9 +363,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             }
             float4 cst = zero4();
             if (tid < NC) cst = bload4<AUX_L2>(rsX, tid < N ? (unsigned)tid * 16u : OOB, offCS);
-            // behind the hand-off reads in the memory pipe: last batch's dE rows out, next batch's rows in
-            if (want_grad && has_spk && seq > 0) GE2E_TEAM_STORE_DE(bi - id.nct);
-            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (dact) put_split4(CHh, CHl, (wid + 8 * u) * PH + d4, cv[u]);
@@ -307,8 +373,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
         f32x4 g[4];                 // dL/dS of this lane's 16 columns (own column removed), P4 -> P6
-        float4 kjp = zero4();       // speaker row KJP_j, this lane's 4 columns
-        float4 cj_row = zero4();    // c-hat_j, this lane's 4 columns
         if (has_spk) {
             // ===== P3: X[k][r] for the wave's own rows ================================================
             const int irow = min(l15, M - 1);
@@ -318,7 +382,21 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-            gemm_x_16rows<D>(CHh, CHl, PH, ETh, ETl, (rbase + irow) * PH, lane, acc);
+            {   // gemm_x_16rows, with the finished dE tiles of prev trickling out: two 16-byte stores per K-step
+                // under an LDS / MFMA-bound loop (dropped by the out-of-range offset when there is nothing to store)
+                const int off_a = l15 * PH + 8 * q;
+                const int off_b = (rbase + irow) * PH + 8 * q;
+#pragma unroll
+                for (int s = 0; s < D / 32; ++s) {
+                    const h8 bh = frag_row(ETh + off_b + 32 * s), bl = frag_row(ETl + off_b + 32 * s);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = mfma3_16(frag_row(CHh + off_a + 16 * t * PH + 32 * s), frag_row(CHl + off_a + 16 * t * PH + 32 * s),
+                                          bh, bl, acc[t]);
+                    bstore4<AUX_NT>(rsGp, vo_de, 64u * (2 * s), dEp[2 * s]);
+                    bstore4<AUX_NT>(rsGp, vo_de, 64u * (2 * s + 1), dEp[2 * s + 1]);
+                }
+            }
             GE2E_PROF(3);
 
             // ===== P4: leave-one-out statistics, S, loss, G = dL/dS ===================================
@@ -425,38 +503,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                     float* r8 = RS + (rbase + l15) * 8;
                     r8[3] = rne * (w * kSplitInv2);           // of the gE accumulator (carries 2^16)
                     r8[4] = c1 * kSplitInv;                   // of the e-hat image value (carries 2^8)
-                    r8[5] = c2 * cs.z * kSplitInv;            // of the c-hat_j image value
+                    r8[5] = c2 * cs.z;                        // of c-hat_j (applied in P8)
                     r8[6] = alpha * inv_m1 * kSplitInv;       // c3: of e-hat_i in the speaker row KJP
                     r8[7] = beta * inv_m1;                    // c4: of s_j
                 }
-                // ===== P5: gE = G . CH from registers; the part of dE that does not need KJ ==========
-                f32x4 gs[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gs[t][e] = g[t][e] * kSplitScale;
-                const GFrag gf = g_to_frag(gs);
-                const int ir = 4 * q + pq;                    // the row this lane holds after the transpose
-                const bool irv = ir < M;
-                const int irc = min(ir, M - 1);
-                const float* r8 = RS + (rbase + irc) * 8;
-                const float ra = r8[3], c1i = r8[4], rci = r8[5];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    o = gemm_g_ch_tile(gf, CHh, CHl, PH, 16 * t, lane, o);
-                    float x[4] = {o[0], o[1], o[2], o[3]};
-                    quad_transpose4(x, lane);
-                    const int col = 16 * t + 4 * cq15;
-                    const float4 e4 = get_join4(ETh, ETl, (rbase + irc) * PH + col);
-                    const float4 c4 = get_join4(CHh, CHl, j * PH + col);
-                    dEp[t] = irv ? make_float4(x[0] * ra + e4.x * c1i + c4.x * rci, x[1] * ra + e4.y * c1i + c4.y * rci,
-                                               x[2] * ra + e4.z * c1i + c4.z * rci, x[3] * ra + e4.w * c1i + c4.w * rci)
-                                 : zero4();
-                }
                 // speaker row KJP_j (this lane's 4 columns)
                 float bsum = 0.f;
-                if (dact) cj_row = scale4(get_join4(CHh, CHl, j * PH + d4), kSplitInv);
+                kjp = zero4();
+                cj_row = dact ? scale4(get_join4(CHh, CHl, j * PH + d4), kSplitInv) : zero4();
                 for (int i = 0; i < M; ++i) {
                     const float c3 = RS[(rbase + i) * 8 + 6];
                     bsum += RS[(rbase + i) * 8 + 7];
@@ -467,6 +521,30 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 }
                 const float bs = bsum * cs.z;
                 kjp.x += bs * cj_row.x; kjp.y += bs * cj_row.y; kjp.z += bs * cj_row.z; kjp.w += bs * cj_row.w;
+                // ===== P5: gE = G . CH from registers; ra gE + c1 e-hat stays in registers =============
+                f32x4 gs[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gs[t][e] = g[t][e] * kSplitScale;
+                const GFrag gf = g_to_frag(gs);
+                const float* r8 = RS + (rbase + irc) * 8;
+                const float ra = irv ? r8[3] : 0.f, c1i = irv ? r8[4] : 0.f;
+                rcs = irv ? r8[5] : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    o = gemm_g_ch_tile(gf, CHh, CHl, PH, 16 * t, lane, o);
+                    float x[4] = {o[0], o[1], o[2], o[3]};
+                    quad_transpose4(x, lane);
+                    const int eoff = (rbase + irc) * PH + 16 * t + 4 * cq15;
+                    const h4 eh = *reinterpret_cast<const h4*>(ETh + eoff), el = *reinterpret_cast<const h4*>(ETl + eoff);
+                    dEp[t] = make_float4(fmaf((float)eh[0], c1i, fmaf((float)el[0], c1i, x[0] * ra)),
+                                         fmaf((float)eh[1], c1i, fmaf((float)el[1], c1i, x[1] * ra)),
+                                         fmaf((float)eh[2], c1i, fmaf((float)el[2], c1i, x[2] * ra)),
+                                         fmaf((float)eh[3], c1i, fmaf((float)el[3], c1i, x[3] * ra)));
+                }
+                rn_j = cs.x; kap_j = cs.y;
             }
         }
 
@@ -484,7 +562,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             bstore4(rsX, 0u, offSC + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
 
-        f32x16 gc[2];
         if (want_grad) {
             // ===== P6: G images (fp16 hi / lo, row-major [row][slot]) over the centroid images ========
             if (has_spk && l15 < M) {
@@ -501,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             __syncthreads();
             GE2E_PROF(6);
             // ===== P7: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ==
+            f32x16 gc[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -513,61 +591,41 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                         gc[b] = mfma3(ah, al, frag_tr(ETh, PH, 16 * s, 64 * sl + 32 * b, lane),
                                       frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lane), gc[b]);
                 }
+            }
+            GE2E_PROF(10);
+            // the next batch's rows are requested here: late enough to stay out of the register peaks of P3..P7,
+            // early enough to land under the publishing stores, the barrier and the first rows of the next P1
+            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
+            if (slice_on) {
                 const float sc = w * kSplitInv2;
+                // The store offsets are recomputed from an opaque copy of the lane id: as loop invariants they
+                // were hoisted, spilled, and every reload then waited for ALL outstanding memory operations
+                // (scratch is VMEM too) -- eight full round trips in a row.
+                int lv = lane;
+                asm volatile("" : "+v"(lv));
+                const int k0 = 32 * kh + 4 * (lv >> 5) + (lv & 3);
+                const unsigned c0b = (unsigned)(64 * sl + 4 * ((lv & 31) >> 2)) * 4u + offGC + (unsigned)id.member * (NC * ROWB);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int k = 32 * kh + 8 * g4 + 4 * h + pq;
+                    const int k = k0 + 8 * g4;
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         float x[4] = {gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]};
                         quad_transpose4(x, lane);
-                        const int col = 64 * sl + 32 * b + 4 * cq31;
-                        bstore4(rsX, k < N ? (unsigned)(k * D + col) * 4u : OOB, offGC + (unsigned)id.member * (NC * ROWB),
+                        bstore4(rsX, k < N ? (unsigned)k * ROWB + c0b : OOB, 128u * b,
                                 make_float4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc));
                     }
                 }
             }
+            GE2E_PROF(11);
+            // the next iteration's P1 rewrites the ET images and its P8 the region of the G images
+            __syncthreads();
+        } else {
+            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
         }
-        team_signal(&fl->c2);                                                             // ---- hand-off 2
         GE2E_PROF(7);
-        if (!team_wait(&fl->c2, target, ctl, SH + 4)) return;
-        GE2E_PROF(8);
-
-        // ===== P8: batch scalars; own speaker's gC -> KJ_j; dE = held part + KJ_j ======================
-        if (id.member == 0 && tid == 0) {
-            float l = 0.f, a = 0.f, c = 0.f;
-            for (int m = 0; m < TEAM; ++m) {
-                const float4 v = bload4<AUX_L2>(rsX, 0u, offSC + (unsigned)m * 16u);
-                l += v.x; a += v.y; c += v.z;
-            }
-            if (p.loss) p.loss[bi] = l;
-            if (p.dw) p.dw[bi] = a;
-            if (p.db) p.db[bi] = c;
-        }
-        if (want_grad && has_spk) {
-            float4 part[TEAM];
-#pragma unroll
-            for (int m = 0; m < TEAM; ++m) part[m] = bload4<AUX_L2>(rsX, vrow, offGC + (unsigned)(m * NC + j) * ROWB);
-            float4 gsum = part[0];
-#pragma unroll
-            for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
-            const float coefc = wave_sum(dot4(gsum, cj_row));
-            const float rn = CST[j * 4 + 0], kap = CST[j * 4 + 1];
-            const float f = kap * coefc, sc = rn / fM;
-            if (dact)
-                *reinterpret_cast<float4*>(KJL + wid * D + d4) =
-                    make_float4((gsum.x - f * cj_row.x) * sc + kjp.x, (gsum.y - f * cj_row.y) * sc + kjp.y,
-                                (gsum.z - f * cj_row.z) * sc + kjp.z, (gsum.w - f * cj_row.w) * sc + kjp.w);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {      // complete rows stay in registers until the next batch's hand-off 1
-                const float4 kj = *reinterpret_cast<const float4*>(KJL + wid * D + 16 * t + 4 * cq15);
-                dEp[t].x += kj.x; dEp[t].y += kj.y; dEp[t].z += kj.z; dEp[t].w += kj.w;
-            }
-        }
-        GE2E_PROF(9);
     }
-    if (want_grad && has_spk && seq > 0) GE2E_TEAM_STORE_DE(id.team + (seq - 1) * id.nct);
-    GE2E_PROF_FLUSH(11)
+    GE2E_PROF_FLUSH(13)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ PHASES = {
     "fused_f32": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
                   "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
     "team": ["P1 rows+publish+signal", "wait 1", "P2 centroids->LDS", "P3 gemm X", "P4 softmax", "P5 gemm gE + part dE + KJP",
-             "P6 G images", "P7 gemm gC + publish + signal", "wait 2", "P8 reduce + dE store"],
+             "P6 G images", "P7c end barrier", "wait 2", "P8 reduce", "P7a gemm gC", "P7b rows request + publish"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -59,7 +59,7 @@ def main():
     loss, dw, db, dE = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32), torch.empty_like(E)
     v, im = _lib.VARIANTS[variant], _lib.IMPLS[args.impl]
     ws = torch.empty(lib.ge2e_workspace_bytes(B, N, M, D, v, im) + 256, dtype=torch.uint8, device=dev)
-    prof = torch.zeros(16, dtype=torch.int64, device=dev)
+    prof = torch.zeros(32, dtype=torch.int64, device=dev)
     lib.ge2e_debug_set_prof(prof.data_ptr())
 
     def run():
