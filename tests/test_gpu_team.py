@@ -1,0 +1,78 @@
+"""GPU: GE2E_IMPL_TEAM (eight workgroups of one XCD per batch) beyond the shared parity tests:
+several batches per team (the rotated software pipeline), uneven speaker counts per member,
+forward-only, and agreement with the one-workgroup-per-batch kernel."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+from oracle import ge2e_oracle as orc
+from test_gpu_parity import run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def GF():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from speaker_embedding_ge2e_loss_amd import functional
+    return functional
+
+
+def test_many_batches_per_team_full_size(GF):
+    """B = 150 at the metric shape: 32 teams, 4-5 batches each -> every stage of the pipeline
+    (prologue, steady state, drain) runs; all outputs written; matches fused_split and the oracle."""
+    B, N, M, D = 150, 64, 10, 256
+    E = orc.synth_embeddings((B, N, M, D), "unit", seed=21)
+    ot = run_hip(GF, E, 10.0, -5.0, impl="team")
+    of = run_hip(GF, E, 10.0, -5.0, impl="fused_split")
+    assert not np.isnan(ot["dE"]).any() and not np.isnan(ot["loss"]).any() and not np.isnan(ot["per"]).any()
+    assert np.allclose(ot["loss"], of["loss"], rtol=2e-6)
+    assert np.allclose(ot["dw"], of["dw"], rtol=2e-5)
+    assert np.allclose(ot["db"], of["db"], atol=2e-5)
+    for i in range(B):
+        assert rel_fro(ot["dE"][i], of["dE"][i]) < 5e-6, i
+    for i in (0, 31, 32, 149):
+        ref = orc.closed_form(E[i], 10.0, -5.0)
+        assert np.allclose(ot["loss"][i], ref["loss"], rtol=2e-5)
+        assert rel_fro(ot["dE"][i], ref["dE"]) < 2e-5
+        assert np.allclose(ot["per"][i], ref["per"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(40, 23, 7, 128), (70, 9, 5, 64), (3, 32, 16, 64), (33, 64, 2, 192), (5, 17, 4, 256)])
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_uneven_members(GF, shape, variant):
+    """N not a multiple of 8 (members with fewer or no speakers), M up to 16, every supported D."""
+    B, N, M, D = shape
+    assert GF.resolve_impl(B, N, M, D, variant, "team") == "team"
+    E = orc.synth_embeddings(shape, "raw", seed=sum(shape))
+    ref = orc.closed_form(E, 6.0, -1.5, variant=variant)
+    o = run_hip(GF, E, 6.0, -1.5, variant, "team")
+    assert np.allclose(o["loss"], ref["loss"], rtol=2e-5), variant
+    assert np.allclose(o["per"], ref["per"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(o["dw"], ref["dw"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(o["db"], ref["db"], atol=1e-4)
+    for i in range(B):
+        assert rel_fro(o["dE"][i], ref["dE"][i]) < 2e-5, (i, variant)
+
+
+def test_forward_only(GF):
+    B, N, M, D = 37, 64, 10, 256
+    E = orc.synth_embeddings((B, N, M, D), "clustered", seed=2)
+    e = torch.as_tensor(E, device="cuda:0")
+    w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
+    o = GF.loss_fwd_bwd(e, w, b, impl="team", need_grad=False, need_per=True)
+    torch.cuda.synchronize()
+    assert o.dE is None
+    ref = orc.closed_form(E, 10.0, -5.0, want_grad=False)
+    assert np.allclose(o.loss.cpu().numpy(), ref["loss"], rtol=2e-5)
+    assert np.allclose(o.per.cpu().numpy(), ref["per"], rtol=1e-4, atol=1e-4)
+
+
+def test_auto_uses_team_for_few_batches(GF):
+    assert GF.resolve_impl(1, 64, 10, 256, "softmax", "auto") == "team"
+    assert GF.resolve_impl(1024, 64, 10, 256, "softmax", "auto") == "fused_split"
+    assert GF.resolve_impl(1, 4, 5, 256, "softmax", "auto") == "fused_split"     # too few speakers for eight members
+    with pytest.raises(RuntimeError):
+        GF.resolve_impl(1, 64, 20, 256, "softmax", "team")                        # M > 16
