@@ -65,7 +65,8 @@ def test_workspace_and_impl_queries(lib):
     assert lib.ge2e_workspace_bytes(1, 4, 1, 8, 0, 0) == 0  # bad shape -> 0
     assert lib.ge2e_workspace_bytes(1, 64, 10, 256, 0, 1) > 64 * 256 * 4
     assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 1) == 1
-    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) in (1, 2, 3, 4)
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) in (1, 2, 3, 4, 5)
+    assert lib.ge2e_workspace_bytes(1, 64, 10, 256, 0, 5) > 8 * 64 * 256 * 4  # team: exchange area, sized without a GPU
     assert lib.ge2e_resolve_impl(1, 64, 1, 256, 0, 0) == -2
     # every impl AUTO can resolve to must report a workspace
     for shape in [(1, 4, 5, 256), (1024, 64, 10, 256), (8, 256, 10, 256), (1, 1024, 10, 768)]:
