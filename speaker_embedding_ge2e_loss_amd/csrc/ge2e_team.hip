@@ -36,6 +36,7 @@ namespace ge2e {
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NC = 64;       // centroid slots
 constexpr int GP = 72;       // G image pitch (halfs)
@@ -124,7 +125,7 @@ TeamWs team_layout(int N, int M, int D) {
     TeamWs L;
     L.spm = (N + TEAM - 1) / TEAM;
     L.rt = (L.spm * M + 15) / 16 * 16;
-    L.chx = 0;                                                // [2][64][D]   published unit centroids * 2^8
+    L.chx = 0;                                                // [2][64] rows of (D hi | D lo) halfs: unit centroids * 2^8
     L.cstx = L.chx + (size_t)2 * NC * D;                      // [2][64][4]   rn, kappa, |s|, |s|^2
     L.gcx = L.cstx + (size_t)2 * NC * 4;                      // [2][8][64][D] partial centroid gradients
     L.scx = L.gcx + (size_t)2 * TEAM * NC * D;                // [2][8][4]    loss, dw, db partials
@@ -255,7 +256,24 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     const int irc = min(ir, M - 1);
     const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;
 
-    GE2E_PROF_DECL(13)
+    // Lane-derived indices are re-derived inside each phase from an opaque copy of the lane id.  As loop
+    // invariants they were hoisted out of the batch loop, spilled under the register peaks, and reloaded from
+    // scratch in the middle of phases -- and a scratch reload is a VMEM load that retires in order BEHIND the
+    // dE stores still in flight.  A handful of VALU ops per phase is far cheaper.
+#define GE2E_TEAM_LANE_IDS()                                                                        \
+    int lv_ = lane;                                                                                 \
+    asm volatile("" : "+v"(lv_));                                                                   \
+    const int l15 = lv_ & 15, q = lv_ >> 4, l31 = lv_ & 31, h = lv_ >> 5, pq = lv_ & 3;             \
+    const int cq15 = (lv_ & 15) >> 2, cq31 = (lv_ & 31) >> 2, d4 = 4 * lv_;                         \
+    const bool dact = d4 < D;                                                                       \
+    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                                           \
+    const int ir = 4 * q + pq;                                                                      \
+    const bool irv = ir < M;                                                                        \
+    const int irc = min(ir, M - 1);                                                                 \
+    const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;                \
+    (void)l15; (void)q; (void)l31; (void)h; (void)pq; (void)cq15; (void)cq31; (void)dact; (void)vrow; \
+    (void)irc; (void)vo_de
+    GE2E_PROF_DECL(16)
     GE2E_TEAM_LOAD_ROWS(id.team);
     for (int seq = 0;; ++seq) {
         const int bi = id.team + seq * id.nct;          // batch started in this iteration
@@ -273,12 +291,30 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 
         // ===== P1(cur): own rows -> ET images, unit centroid -> team ===================================
         if (has_spk && have_cur) {
+            GE2E_TEAM_LANE_IDS();
+            // centroid first: its stores (and prev's partial gradients behind them) drain under the row work below
             float4 s = zero4();
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
+            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float sq = wave_sum(dot4(c, c));
+            const float ss = wave_sum(dot4(s, s));
+            float rn, kap;
+            unit_stats(sq, eps_cos, rn, kap);
+            {   // published as the finished fp16 images (row = D hi halfs, then D lo halfs): members only copy
+                h4 hi, lo;
+                split4(scale4(c, rn * kSplitScale), hi, lo);
+                const unsigned vh = dact ? (unsigned)d4 * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + offCH + (unsigned)j * ROWB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + offCH + (unsigned)j * ROWB + 2u * D, 0, 0);
+            }
+            // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
+            bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float4 e = rowv[i];
-                    s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
                     const float ee = wave_sum(dot4(e, e));
                     float rne, ke;
                     unit_stats_fast(ee, eps_cos, rne, ke);
@@ -286,14 +322,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                     if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, 0.f);
                 }
             }
-            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
-            const float sq = wave_sum(dot4(c, c));
-            const float ss = wave_sum(dot4(s, s));
-            float rn, kap;
-            unit_stats(sq, eps_cos, rn, kap);
-            bstore4(rsX, vrow, offCH + (unsigned)j * ROWB, scale4(c, rn * kSplitScale));
-            // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
-            bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
         }
         // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,6 +347,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 if (p.db) p.db[bi - id.nct] = c;
             }
             if (want_grad && has_spk) {
+                GE2E_TEAM_LANE_IDS();
                 float4 part[TEAM];
 #pragma unroll
                 for (int m = 0; m < TEAM; ++m) part[m] = bload4<AUX_L2>(rsX, vrow, offGCp + (unsigned)(m * NC + j) * ROWB);
@@ -345,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         }
         if (!have_cur) {   // drain: the last batch's rows go out in one piece
             if (want_grad && has_spk) {
+                GE2E_TEAM_LANE_IDS();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bstore4<AUX_NT>(rsGp, vo_de, 64u * t, dEp[t]);
             }
@@ -355,25 +385,31 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         if (!team_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4)) return;
         GE2E_PROF(1);
         {
-            float4 cv[8];
+            GE2E_TEAM_LANE_IDS();
+            float4 cv[8];     // 8 halfs of a published image row per lane: lanes below D / 8 hold hi, the next D / 8 lo
+            const bool cact = 8 * lane < 2 * D;
+            const bool chi = 8 * lane < D;
+            const int ccol = chi ? 8 * lane : 8 * lane - D;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = wid + 8 * u;
-                cv[u] = bload4<AUX_L2>(rsX, k < N ? vrow : OOB, offCH + (unsigned)min(k, N - 1) * ROWB);
+                cv[u] = bload4<AUX_L2>(rsX, (k < N && cact) ? (unsigned)lane * 16u : OOB, offCH + (unsigned)min(k, N - 1) * ROWB);
             }
             float4 cst = zero4();
             if (tid < NC) cst = bload4<AUX_L2>(rsX, tid < N ? (unsigned)tid * 16u : OOB, offCS);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (dact) put_split4(CHh, CHl, (wid + 8 * u) * PH + d4, cv[u]);
+                if (cact) *reinterpret_cast<float4*>((chi ? CHh : CHl) + (wid + 8 * u) * PH + ccol) = cv[u];
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cst;
         }
         __syncthreads();
         GE2E_PROF(2);
 
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        f32x4 g[4];                 // dL/dS of this lane's 16 columns (own column removed), P4 -> P6
+        GFrag gf;                   // dL/dS (own column removed) * 2^8 of this lane's 16 columns as fp16 hi / lo: the A
+                                    // operand of P5 and, bit for bit, what P6 writes as the G images
         if (has_spk) {
+            GE2E_TEAM_LANE_IDS();
             // ===== P3: X[k][r] for the wave's own rows ================================================
             const int irow = min(l15, M - 1);
             const bool rv = l15 < M;
@@ -399,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             }
             GE2E_PROF(3);
 
+            f32x4 g[4];
             // ===== P4: leave-one-out statistics, S, loss, G = dL/dS ===================================
             const float4 rs0 = *reinterpret_cast<const float4*>(RS + (rbase + irow) * 8);  // rne ke ee
             const float rne = rv ? rs0.x : 0.f, ke = rs0.y, ee = rs0.z;
@@ -504,21 +541,35 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                     r8[3] = rne * (w * kSplitInv2);           // of the gE accumulator (carries 2^16)
                     r8[4] = c1 * kSplitInv;                   // of the e-hat image value (carries 2^8)
                     r8[5] = c2 * cs.z;                        // of c-hat_j (applied in P8)
-                    r8[6] = alpha * inv_m1 * kSplitInv;       // c3: of e-hat_i in the speaker row KJP
-                    r8[7] = beta * inv_m1;                    // c4: of s_j
                 }
-                // speaker row KJP_j (this lane's 4 columns)
-                float bsum = 0.f;
+                // speaker row KJP_j (this lane's 4 columns).  The row coefficients sit in lane i (= row i) of every
+                // 16-lane group: c3_i is broadcast with v_readlane, sum_i c4_i is a 16-lane DPP sum -- no LDS trip,
+                // and the M image rows are requested back to back.
+                const float c3v = alpha * inv_m1 * kSplitInv, c4v = rv ? beta * inv_m1 : 0.f;
+                const float bsum = row16_sum(c4v);
                 kjp = zero4();
                 cj_row = dact ? scale4(get_join4(CHh, CHl, j * PH + d4), kSplitInv) : zero4();
-                for (int i = 0; i < M; ++i) {
-                    const float c3 = RS[(rbase + i) * 8 + 6];
-                    bsum += RS[(rbase + i) * 8 + 7];
-                    if (dact) {
-                        const float4 e = get_join4(ETh, ETl, (rbase + i) * PH + d4);
-                        kjp.x += c3 * e.x; kjp.y += c3 * e.y; kjp.z += c3 * e.z; kjp.w += c3 * e.w;
+#pragma unroll
+                for (int i0 = 0; i0 < MR; i0 += 4) {          // four rows in flight (8 VGPRs of fragments)
+                    h4 eh[4], el[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int off = (rbase + min(i0 + u, M - 1)) * PH + min(d4, D - 4);
+                        eh[u] = *reinterpret_cast<const h4*>(ETh + off);
+                        el[u] = *reinterpret_cast<const h4*>(ETl + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + u < MR) {
+                            const float c3 = i0 + u < M ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3v), i0 + u)) : 0.f;
+                            kjp.x = fmaf((float)eh[u][0], c3, fmaf((float)el[u][0], c3, kjp.x));
+                            kjp.y = fmaf((float)eh[u][1], c3, fmaf((float)el[u][1], c3, kjp.y));
+                            kjp.z = fmaf((float)eh[u][2], c3, fmaf((float)el[u][2], c3, kjp.z));
+                            kjp.w = fmaf((float)eh[u][3], c3, fmaf((float)el[u][3], c3, kjp.w));
+                        }
                     }
                 }
+                if (!dact) kjp = zero4();
                 const float bs = bsum * cs.z;
                 kjp.x += bs * cj_row.x; kjp.y += bs * cj_row.y; kjp.z += bs * cj_row.z; kjp.w += bs * cj_row.w;
                 // ===== P5: gE = G . CH from registers; ra gE + c1 e-hat stays in registers =============
@@ -527,27 +578,55 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) gs[t][e] = g[t][e] * kSplitScale;
-                const GFrag gf = g_to_frag(gs);
+                gf = g_to_frag(gs);
                 const float* r8 = RS + (rbase + irc) * 8;
                 const float ra = irv ? r8[3] : 0.f, c1i = irv ? r8[4] : 0.f;
                 rcs = irv ? r8[5] : 0.f;
+                // Three tiles are in flight, written out by hand because the compiler serialises the chain
+                // (LDS -> wait -> 6 dependent MFMAs -> wait -> transpose / epilogue, ~1000 cycles a tile): the
+                // fragments of tile t + 1 are requested, then the MFMAs of tile t issue, then the VALU epilogue
+                // of tile t - 1 runs underneath them.
+                h8 fb[2][4];        // [parity][CH hi K-step 0, lo 0, hi 1, lo 1]
+                h4 ee[3][2];        // [tile % 3][e-hat hi, lo] of this lane's row, 4 columns (live across three stages)
+                f32x4 ot[2];
+                const int eoff0 = (rbase + irc) * PH + 4 * cq15;
+#define GE2E_TEAM_P5_LOAD(T)                                                                     \
+    do {                                                                                         \
+        fb[(T) & 1][0] = frag_tr16(CHh, PH, 0, 16 * (T), lv_);                                  \
+        fb[(T) & 1][1] = frag_tr16(CHl, PH, 0, 16 * (T), lv_);                                  \
+        fb[(T) & 1][2] = frag_tr16(CHh, PH, 1, 16 * (T), lv_);                                  \
+        fb[(T) & 1][3] = frag_tr16(CHl, PH, 1, 16 * (T), lv_);                                  \
+        ee[(T) % 3][0] = *reinterpret_cast<const h4*>(ETh + eoff0 + 16 * (T));                   \
+        ee[(T) % 3][1] = *reinterpret_cast<const h4*>(ETl + eoff0 + 16 * (T));                   \
+    } while (0)
+#define GE2E_TEAM_P5_EPI(T)                                                                      \
+    do {                                                                                         \
+        float x_[4] = {ot[(T) & 1][0], ot[(T) & 1][1], ot[(T) & 1][2], ot[(T) & 1][3]};          \
+        quad_transpose4(x_, lv_);                                                               \
+        const h4 eh_ = ee[(T) % 3][0], el_ = ee[(T) % 3][1];                                     \
+        dEp[T] = make_float4(fmaf((float)eh_[0], c1i, fmaf((float)el_[0], c1i, x_[0] * ra)),    \
+                             fmaf((float)eh_[1], c1i, fmaf((float)el_[1], c1i, x_[1] * ra)),    \
+                             fmaf((float)eh_[2], c1i, fmaf((float)el_[2], c1i, x_[2] * ra)),    \
+                             fmaf((float)eh_[3], c1i, fmaf((float)el_[3], c1i, x_[3] * ra)));   \
+    } while (0)
+                GE2E_PROF(12);
+                GE2E_TEAM_P5_LOAD(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    if (t + 1 < NT) GE2E_TEAM_P5_LOAD(t + 1);
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    o = gemm_g_ch_tile(gf, CHh, CHl, PH, 16 * t, lane, o);
-                    float x[4] = {o[0], o[1], o[2], o[3]};
-                    quad_transpose4(x, lane);
-                    const int eoff = (rbase + irc) * PH + 16 * t + 4 * cq15;
-                    const h4 eh = *reinterpret_cast<const h4*>(ETh + eoff), el = *reinterpret_cast<const h4*>(ETl + eoff);
-                    dEp[t] = make_float4(fmaf((float)eh[0], c1i, fmaf((float)el[0], c1i, x[0] * ra)),
-                                         fmaf((float)eh[1], c1i, fmaf((float)el[1], c1i, x[1] * ra)),
-                                         fmaf((float)eh[2], c1i, fmaf((float)el[2], c1i, x[2] * ra)),
-                                         fmaf((float)eh[3], c1i, fmaf((float)el[3], c1i, x[3] * ra)));
+                    o = mfma3_16(gf.hi[0], gf.lo[0], fb[t & 1][0], fb[t & 1][1], o);
+                    o = mfma3_16(gf.hi[1], gf.lo[1], fb[t & 1][2], fb[t & 1][3], o);
+                    if (t > 0) GE2E_TEAM_P5_EPI(t - 1);
+                    ot[t & 1] = o;
                 }
+                GE2E_TEAM_P5_EPI(NT - 1);
+                GE2E_PROF(13);
                 rn_j = cs.x; kap_j = cs.y;
             }
         }
 
+        GE2E_TEAM_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under P6 / P7 and the hand-offs
         // ---- member scalars: fixed-order reduction over the 8 waves ----------------------------------
         loss_acc = wave_sum(loss_acc);
         dw_acc = wave_sum(dw_acc);
@@ -564,11 +643,20 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 
         if (want_grad) {
             // ===== P6: G images (fp16 hi / lo, row-major [row][slot]) over the centroid images ========
-            if (has_spk && l15 < M) {
+            if (has_spk) {
+                GE2E_TEAM_LANE_IDS();
+                if (l15 < M) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    put_split4(Gh, Gl, (rbase + l15) * GP + 16 * t + 4 * q,
-                               make_float4(g[t][0] * kSplitScale, g[t][1] * kSplitScale, g[t][2] * kSplitScale, g[t][3] * kSplitScale));
+                for (int s2 = 0; s2 < 2; ++s2) {      // K-step s2 of the fragment = column blocks 2 s2 and 2 s2 + 1
+                    const uint4 hh = __builtin_bit_cast(uint4, gf.hi[s2]), ll = __builtin_bit_cast(uint4, gf.lo[s2]);
+                    _Float16* gh = Gh + (rbase + l15) * GP + 32 * s2 + 4 * q;
+                    _Float16* gl = Gl + (rbase + l15) * GP + 32 * s2 + 4 * q;
+                    *reinterpret_cast<uint2*>(gh) = make_uint2(hh.x, hh.y);
+                    *reinterpret_cast<uint2*>(gh + 16) = make_uint2(hh.z, hh.w);
+                    *reinterpret_cast<uint2*>(gl) = make_uint2(ll.x, ll.y);
+                    *reinterpret_cast<uint2*>(gl + 16) = make_uint2(ll.z, ll.w);
+                }
+                }
             }
             for (int i = tid; i < (RT - R_my) * (GP / 8); i += 512) {    // rows without an embedding
                 const int r = R_my + i / (GP / 8), c8 = (i % (GP / 8)) * 8;
@@ -584,18 +672,16 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
             if (slice_on) {
+                GE2E_TEAM_LANE_IDS();
                 for (int s = 0; s < RT / 16; ++s) {
-                    const h8 ah = frag_tr(Gh, GP, 16 * s, 32 * kh, lane), al = frag_tr(Gl, GP, 16 * s, 32 * kh, lane);
+                    const h8 ah = frag_tr(Gh, GP, 16 * s, 32 * kh, lv_), al = frag_tr(Gl, GP, 16 * s, 32 * kh, lv_);
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        gc[b] = mfma3(ah, al, frag_tr(ETh, PH, 16 * s, 64 * sl + 32 * b, lane),
-                                      frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lane), gc[b]);
+                        gc[b] = mfma3(ah, al, frag_tr(ETh, PH, 16 * s, 64 * sl + 32 * b, lv_),
+                                      frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lv_), gc[b]);
                 }
             }
             GE2E_PROF(10);
-            // the next batch's rows are requested here: late enough to stay out of the register peaks of P3..P7,
-            // early enough to land under the publishing stores, the barrier and the first rows of the next P1
-            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
             if (slice_on) {
                 const float sc = w * kSplitInv2;
                 // The store offsets are recomputed from an opaque copy of the lane id: as loop invariants they
@@ -611,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         float x[4] = {gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]};
-                        quad_transpose4(x, lane);
+                        quad_transpose4(x, lv);
                         bstore4(rsX, k < N ? (unsigned)k * ROWB + c0b : OOB, 128u * b,
                                 make_float4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc));
                     }
@@ -620,12 +706,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
             GE2E_PROF(11);
             // the next iteration's P1 rewrites the ET images and its P8 the region of the G images
             __syncthreads();
-        } else {
-            GE2E_TEAM_LOAD_ROWS(bi + id.nct);
         }
         GE2E_PROF(7);
     }
-    GE2E_PROF_FLUSH(13)
+    GE2E_PROF_FLUSH(16)
 }
 
 // ---------------------------------------------------------------------------------------------
