@@ -92,9 +92,11 @@ def measured_traffic(cfg_name, impl, B):
     was measured on, otherwise null."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get(cfg_name)
-        if t and t["impl"] == impl and t["batches_per_launch"] == B:
-            return t["fetch_bytes"] + t["write_bytes"]
+            table = json.load(f)
+        for key in (cfg_name, f"{cfg_name}_{impl}"):
+            t = table.get(key)
+            if t and t["impl"] == impl and t["batches_per_launch"] == B:
+                return t["fetch_bytes"] + t["write_bytes"]
     except Exception:
         pass
     return None

@@ -21,9 +21,9 @@ unsigned long long* g_prof = nullptr;  // diagnostic build only
 
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
-// AUTO: few batches -> a team of eight CUs per batch (measured at N=64, M=10, D=256: 58 us vs 126 us for
-// B = 1, 101 us vs 136 us for B = 64, break-even at B ~ 128); many batches -> one workgroup per batch.
-constexpr int kTeamMaxB = 96;
+// AUTO: few batches -> a team of eight CUs per batch (measured at N=64, M=10, D=256: 53 us vs 126 us for
+// B = 1, 96 us vs 136 us for B = 64, break-even at B = 128); many batches -> one workgroup per batch.
+constexpr int kTeamMaxB = 128;
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;

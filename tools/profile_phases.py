@@ -78,6 +78,8 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     cyc = prof.cpu().numpy().astype(float) / B
+    if args.impl == "team":
+        cyc /= 8.0          # eight workgroups stamp every batch; report one workgroup's timeline
     tot = cyc.sum()
     names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])
     print(f"{args.impl} {args.config} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
