@@ -111,7 +111,7 @@ int ge2e_selftest_wave_ops(const float* x, float* out, void* stream);
  * accumulators, GT = GE stored through the in-quad register transpose. */
 int ge2e_selftest_rows16(const float* CH, const float* R, float* XT, float* GE, float* GT, void* stream);
 /* Team formation (8 workgroups of one XCD) + the L2 hand-off protocol under load: `grid` workgroups
- * (cooperative launch), `rounds` publish/consume rounds of `payload_f4` float4 per member.
+ * (all resident), `rounds` publish/consume rounds of `payload_f4` float4 per member.
  * out [16] (device): [0] complete teams, [1] mismatching float4 read back, [2..9] workgroups per XCD,
  * [10] abort word.  ws: ge2e_selftest_team_bytes(payload_f4) bytes, 256-byte aligned. */
 size_t ge2e_selftest_team_bytes(int payload_f4);

@@ -21,9 +21,10 @@ unsigned long long* g_prof = nullptr;  // diagnostic build only
 
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
-// AUTO: few batches -> a team of eight CUs per batch (measured at N=64, M=10, D=256: 53 us vs 126 us for
-// B = 1, 96 us vs 136 us for B = 64, break-even at B = 128); many batches -> one workgroup per batch.
-constexpr int kTeamMaxB = 128;
+// AUTO: few batches -> a team of eight CUs per batch (measured at N=64, M=10, D=256, back-to-back launches:
+// 38 us vs 128 us for B = 1, 76 us vs 136 us for B = 64, 126 us vs 146 us for B = 128, break-even at
+// B ~ 150); many batches -> one workgroup per batch.
+constexpr int kTeamMaxB = 144;
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;

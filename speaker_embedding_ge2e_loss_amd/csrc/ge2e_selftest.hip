@@ -192,9 +192,15 @@ hipError_t launch_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds,
     TeamCtl* ctl = reinterpret_cast<TeamCtl*>(ws);
     TeamFlags* flags = reinterpret_cast<TeamFlags*>(ctl + 1);
     float4* data = reinterpret_cast<float4*>(flags + 64);
-    void* args[] = {&ctl, &flags, &data, &rounds, &payload, &out};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ge2e_selftest_team_kernel), dim3(grid), dim3(512),
-                                      args, 0, stream);
+    // all workgroups must be resident (see launch_nch in ge2e_team.hip): checked here, then an ordinary launch
+    int per_cu = 0, dev = 0, cus = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(ge2e_selftest_team_kernel), 512, 0);
+    if (err != hipSuccess) return err;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return hipErrorInvalidDevice;
+    if (grid > per_cu * cus) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(ge2e_selftest_team_kernel, dim3(grid), dim3(512), 0, stream, ctl, flags, data, rounds, payload, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest_split(const float* A, const float* Bm, const float* G, float* X, float* GE, float* GC,

@@ -720,8 +720,22 @@ static hipError_t launch_nch(Problem& p, TeamWs& L, hipStream_t stream) {
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
     if (err != hipSuccess) return err;
-    void* args[] = {&p, &L};
-    return hipLaunchCooperativeKernel(fn, dim3(team_grid(p.B)), dim3(512), args, L.lds_bytes, stream);
+    // Every workgroup must be resident (they wait for each other).  That is what a cooperative launch checks --
+    // grid <= resident capacity -- and all it does on this platform; the same check is made here and the kernel
+    // goes out as an ordinary launch (rocprofv3 7.2 crashes at process exit after a cooperative launch, and the
+    // ordinary path is a few microseconds cheaper).  Spins in the kernel are bounded either way.
+    static int resident_per_cu[5][2] = {};
+    int& per_cu = resident_per_cu[NCH][MR == MAXM];
+    if (per_cu == 0) {
+        int nb = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
+        if (err != hipSuccess) return err;
+        per_cu = nb > 0 ? nb : -1;
+    }
+    const int grid = team_grid(p.B);
+    if (per_cu < 0 || grid > per_cu * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    return hipGetLastError();
 }
 
 hipError_t launch_team(const Problem& p_in, hipStream_t stream) {

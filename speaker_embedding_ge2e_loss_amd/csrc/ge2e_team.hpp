@@ -1,6 +1,6 @@
 // Building blocks of GE2E_IMPL_TEAM: eight workgroups on eight CUs of ONE XCD share a batch.
 //
-//  * Team formation.  The kernel is launched cooperatively (every workgroup resident, one per CU
+//  * Team formation.  Every workgroup of the launch is resident (the host checks grid <= resident capacity, one per CU
 //    because of its LDS footprint).  A workgroup reads the id of the XCD it landed on, takes a
 //    ticket from that XCD's counter and waits until all workgroups of the grid have done so; the
 //    final per-XCD counts then tell every workgroup the same story: tickets 8q..8q+7 of an XCD form
