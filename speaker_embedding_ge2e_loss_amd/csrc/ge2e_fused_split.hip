@@ -13,12 +13,12 @@
 //     phase splits its rows over 8 waves; the gradient contractions give each wave a 32 x 64
 //     block (two waves share a SIMD's matrix pipe); X (four 32 x 32 tiles) stays on waves 0-3.
 //
-//   LDS (D=256: 159 KB)            fp16 images, pitch D+8 halfs (16-B aligned rows, b128 conflict-free)
-//     CHh, CHl [64][D+8]   unit centroids * 2^8, hi / lo
-//     ETh, ETl [64][D+8]   the tile's unit embeddings * 2^8, hi / lo  (fp32 gC staging in finalize)
+//   LDS (D=256: 157 KB)            fp16 images, pitch D+16 halfs (16-B aligned rows, conflict-free for b128 and tr reads)
+//     CHh, CHl [64][D+16]   unit centroids * 2^8, hi / lo
+//     ETh, ETl [64][D+16]   the tile's unit embeddings * 2^8, hi / lo  (fp32 gC staging in finalize)
 //     U        18 KB       union: S [64][68] fp32 (similarities)  |  Gh, Gl [64][72] fp16 (G_off * 2^8)
 //                                 |  the epilogue's 8 x [8][68] fp32 staging blocks
-//     KJ [6][D], RS [64][8], CST [64][4] fp32
+//     RS [64][8], CST [64][4] fp32
 //
 // Leave-one-out statistics come out of the similarity tile instead of extra dot products: the
 // own-speaker column of X is c-hat_j . e-hat_r, so  e.s_j = X |s_j| |e|,
@@ -110,8 +110,8 @@ __device__ __forceinline__ float4 get_join4(const _Float16* hi_img, const _Float
 }  // namespace
 
 size_t fused_split_lds_bytes(int D) {
-    const int PH = D + 8;
-    return (size_t)4 * 64 * PH * 2 + (size_t)2 * 64 * GP * 2 + (size_t)(MAX_SPT * D + TR * 8 + NC * 4 + 32) * sizeof(float);
+    const int PH = D + 16;
+    return (size_t)4 * 64 * PH * 2 + (size_t)2 * 64 * GP * 2 + (size_t)(TR * 8 + NC * 4 + 32) * sizeof(float);
 }
 
 template <int NCH>  // D = 64 * NCH
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D + 4;    // fp32 pitch of the gC staging that reuses the ET images in finalize
-    constexpr int PH = D + 8;   // fp16 image pitch
+    constexpr int PH = D + 16;  // fp16 image pitch: rows 8 banks apart (mod 64) -> neither the b128 row reads nor the
+                                // 4-row x 32-byte transposing reads collide (D + 8 cost 39 % of the LDS cycles in conflicts)
     constexpr unsigned ROWB = D * 4;  // bytes per embedding row
     _Float16* const CHh = reinterpret_cast<_Float16*>(smem_f);
     _Float16* const CHl = CHh + NC * PH;
@@ -129,8 +130,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     float* const AT = reinterpret_cast<float*>(ETl + TR * PH); // U region as S / staging: [64][68] fp32
     _Float16* const Gh = reinterpret_cast<_Float16*>(AT);      // U region as G images
     _Float16* const Gl = Gh + TR * GP;
-    float* const KJ = AT + (2 * TR * GP * 2) / 4;
-    float* const RS = KJ + MAX_SPT * D;
+    float* const RS = AT + (2 * TR * GP * 2) / 4;
     float* const CST = RS + TR * 8;
     float* const RED = CST + NC * 4;
     static_assert(2 * TR * GP * 2 >= TR * APITCH * 4, "U region must hold the fp32 S tile");

@@ -131,7 +131,7 @@ TeamWs team_layout(int N, int M, int D) {
     L.scx = L.gcx + (size_t)2 * TEAM * NC * D;                // [2][8][4]    loss, dw, db partials
     L.stride = align_up(L.scx + (size_t)2 * TEAM * 4, 64);
     L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(TeamFlags), 256);
-    const int PH = D + 8;
+    const int PH = D + 16;
     L.lds_bytes = (size_t)(2 * NC * PH + 2 * L.rt * PH) * 2 + (size_t)(L.rt * 8 + NC * 4 + 32 + 8) * sizeof(float);
     return L;
 }
@@ -164,7 +164,7 @@ template <int NCH, int MR>  // D = 64 * NCH; MR >= M rows of a speaker are held 
 __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
-    constexpr int PH = D + 8;
+    constexpr int PH = D + 16;            // image pitch: rows 8 banks apart, conflict-free for b128 row reads AND tr reads
     constexpr unsigned ROWB = D * 4;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
     const int RT = L.rt;
