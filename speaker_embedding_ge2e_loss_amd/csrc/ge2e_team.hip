@@ -116,8 +116,11 @@ __device__ __forceinline__ void col4_argmax(float& v, int& i) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+static int team_cu_count();
+
 bool team_supports(int N, int M, int D) {
     if (!(N >= 1 && N <= NC && M >= 2 && M <= MAXM && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
+    if (team_cu_count() < MAX_XCD * TEAM) return false;      // partitioned device: no XCD-wide teams to form
     return team_layout(N, M, D).lds_bytes <= 160 * 1024;
 }
 
@@ -273,8 +276,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;                \
     (void)l15; (void)q; (void)l31; (void)h; (void)pq; (void)cq15; (void)cq31; (void)dact; (void)vrow; \
     (void)irc; (void)vo_de
-    GE2E_PROF_DECL(16)
+    // a bounded spin ran out (a member never arrived): make the failure loud in the outputs before leaving
+#define GE2E_TEAM_FAIL()                                                             \
+    do {                                                                             \
+        for (int i_ = tid; i_ < p.B; i_ += 512) p.loss[i_] = __builtin_nanf("");     \
+    } while (0)
+    GE2E_PROF_DECL(10)
     GE2E_TEAM_LOAD_ROWS(id.team);
+    bool failed = false;
     for (int seq = 0;; ++seq) {
         const int bi = id.team + seq * id.nct;          // batch started in this iteration
         const bool have_cur = bi < p.B, have_prev = seq > 0;
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
 
         // ===== P8(prev): batch scalars; own speaker's gC -> KJ_j; the held rows of dE become complete ==
         if (have_prev) {
-            if (!team_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4)) return;
+            if (!team_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4)) { failed = true; break; }
             GE2E_PROF(8);
             if (id.member == 0 && tid == 0) {
                 float l = 0.f, a = 0.f, c = 0.f;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         }
 
         // ===== P2(cur): the 64 published unit centroids -> CH images (slots >= N are zero) ==============
-        if (!team_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4)) return;
+        if (!team_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4)) { failed = true; break; }
         GE2E_PROF(1);
         {
             GE2E_TEAM_LANE_IDS();
@@ -609,7 +618,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                              fmaf((float)eh_[2], c1i, fmaf((float)el_[2], c1i, x_[2] * ra)),    \
                              fmaf((float)eh_[3], c1i, fmaf((float)el_[3], c1i, x_[3] * ra)));   \
     } while (0)
-                GE2E_PROF(12);
                 GE2E_TEAM_P5_LOAD(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -621,7 +629,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                     ot[t & 1] = o;
                 }
                 GE2E_TEAM_P5_EPI(NT - 1);
-                GE2E_PROF(13);
                 rn_j = cs.x; kap_j = cs.y;
             }
         }
@@ -681,7 +688,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                                       frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lv_), gc[b]);
                 }
             }
-            GE2E_PROF(10);
             if (slice_on) {
                 const float sc = w * kSplitInv2;
                 // The store offsets are recomputed from an opaque copy of the lane id: as loop invariants they
@@ -703,13 +709,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
                     }
                 }
             }
-            GE2E_PROF(11);
             // the next iteration's P1 rewrites the ET images and its P8 the region of the G images
             __syncthreads();
         }
         GE2E_PROF(7);
     }
-    GE2E_PROF_FLUSH(16)
+    if (failed) GE2E_TEAM_FAIL();
+    GE2E_PROF_FLUSH(10)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -24,8 +24,10 @@ import bench  # noqa: E402
 PHASES = {
     "fused_f32": ["s1 centroids", "s2a stage+stats", "s2b gemm1 X", "s2c softmax", "s2d gemm3 gC",
                   "finalize dc", "s3a stage", "s3b/c KJ+gemm2", "s3d epilogue", "-"],
-    "team": ["P1 rows+publish+signal", "wait 1", "P2 centroids->LDS", "P3 gemm X", "P4 softmax", "P5c scalars + barrier",
-             "P6 G images", "P7c end barrier", "wait 2", "P8 reduce", "P7a gemm gC", "P7b rows request + publish", "P5a coefficients + KJP", "P5b gE tiles"],
+    "team": ["P1(cur) rows -> images, centroid out; drain + signals", "wait 1 (centroids of all members)",
+             "P2 centroid images -> LDS", "P3 X = CH.ET^T (+ dE stores of prev)", "P4 softmax in registers",
+             "P5 KJP, gE tiles, scalars + barrier", "P6 G images", "P7 partial gC, rows request, publish, barrier",
+             "wait 2 (partial gradients of prev)", "P8(prev) reduce -> KJ, dE complete"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
