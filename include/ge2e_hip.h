@@ -95,6 +95,12 @@ int ge2e_cos_sim(const float* E, int B, int N, int M, int D,
 int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant,
                    float* loss, float* per_emb_loss, void* stream);
 
+/* GE2ELoss.get_cos_sim(embeddings, centroids, hp) (s3:42-80) with the CALLER'S centroids C [B][N][D]: other-speaker
+ * columns use C, the own-speaker column the leave-one-out centroid of E; + eps on every entry.  cos [B][N][M][N].
+ * (ge2e_cos_sim above is the special case C = get_centroids(E), the only one the reference's callers use.) */
+int ge2e_cos_sim_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos,
+                           float eps, float* cos, void* stream);
+
 /* GE2ELoss.get_centroids (s3:34-38): cent [B][N][D] = mean over M. */
 int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream);
 

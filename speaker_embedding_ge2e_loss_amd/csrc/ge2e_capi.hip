@@ -136,6 +136,14 @@ int ge2e_cos_sim(const float* E, int B, int N, int M, int D, float eps_cos, floa
     return run(p, GE2E_IMPL_GENERIC, workspace, workspace_bytes, stream);
 }
 
+// get_cos_sim with the caller's centroids (the reference's second argument), forward only.
+int ge2e_cos_sim_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos, float eps,
+                           float* cos, void* stream) {
+    if (!E || !C || !cos) return GE2E_ERR_NULL;
+    if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
+    return (int)launch_cos_centroids(E, C, B, N, M, D, eps_cos, eps, cos, (hipStream_t)stream);
+}
+
 int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
                    float* per_emb_loss, void* stream) {
     if (!sim || !loss) return GE2E_ERR_NULL;

@@ -228,6 +228,56 @@ __global__ void ge2e_centroids_kernel(const float* E, int rows /*B*N*/, int M, i
     }
 }
 
+// get_cos_sim with CALLER-SUPPLIED centroids (s3:42-80 uses its `centroids` argument for every other-speaker
+// column and the leave-one-out centroid of `embeddings` on the own-speaker column): one wave per row r = (j, i).
+//   cos[r][k] = e_r . c_k / (max(|e_r|, eps_cos) max(|c_k|, eps_cos)) + eps            (k != j)
+//   cos[r][j] = e_r . u_r / (max(|e_r|, eps_cos) max(|u_r|, eps_cos)) + eps,  u_r = (sum_i' e_ji' - e_r) / (M - 1)
+// E [B][N][M][D], C [B][N][D] -> cos [B][N][M][N].  A forward-only helper (the eval script's path), not a hot path.
+__global__ __launch_bounds__(256) void ge2e_cos_centroids_kernel(const float* E, const float* C, int B, int N, int M,
+                                                                  int D, float eps_cos, float eps, float* cos) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const size_t rows = (size_t)B * N * M;
+    for (size_t r = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
+        const size_t bj = r / M;                    // (batch, speaker)
+        const int j = (int)(bj % N);
+        const size_t bi = bj / N;
+        const float* e = E + r * D;
+        const float* spk = E + bj * (size_t)M * D;
+        const float inv_m1 = 1.0f / (float)(M - 1);
+        float ee = 0.f, eu = 0.f, uu = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float s = 0.f;
+            for (int i = 0; i < M; ++i) s += spk[(size_t)i * D + d];
+            const float x = e[d], u = (s - x) * inv_m1;
+            ee = fmaf(x, x, ee); eu = fmaf(x, u, eu); uu = fmaf(u, u, uu);
+        }
+        ee = wave_sum(ee); eu = wave_sum(eu); uu = wave_sum(uu);
+        const float ne = fmaxf(sqrtf(ee), eps_cos);
+        for (int k = 0; k < N; ++k) {
+            float out;
+            if (k == j) {
+                out = eu / (ne * fmaxf(sqrtf(uu), eps_cos));
+            } else {
+                const float* c = C + (bi * N + k) * (size_t)D;
+                float ec = 0.f, cc = 0.f;
+                for (int d = lane; d < D; d += 64) { const float y = c[d]; ec = fmaf(e[d], y, ec); cc = fmaf(y, y, cc); }
+                ec = wave_sum(ec); cc = wave_sum(cc);
+                out = ec / (ne * fmaxf(sqrtf(cc), eps_cos));
+            }
+            if (lane == 0) cos[r * N + k] = out + eps;
+        }
+    }
+}
+
+hipError_t launch_cos_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos, float eps,
+                                float* cos, hipStream_t stream) {
+    const size_t rows = (size_t)B * N * M;
+    const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    hipLaunchKernelGGL(ge2e_cos_centroids_kernel, dim3(grid), dim3(256), 0, stream, E, C, B, N, M, D, eps_cos, eps, cos);
+    return hipGetLastError();
+}
+
 // calc_loss (s3:115-127) on an explicit similarity matrix: one wave per (speaker, utterance)
 // row, one workgroup per batch so the batch sum is a fixed-order reduction.
 __global__ __launch_bounds__(256) void ge2e_calc_loss_kernel(const float* sim, int B, int N, int M,

@@ -30,6 +30,8 @@ size_t generic_workspace_bytes(int B, int N, int M, int D);
 hipError_t launch_generic(const Problem& p, hipStream_t stream);
 hipError_t launch_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
                             float* per, hipStream_t stream);
+hipError_t launch_cos_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos, float eps,
+                                float* cos, hipStream_t stream);
 hipError_t launch_centroids(const float* E, int B, int N, int M, int D, float* cent, hipStream_t stream);
 
 }  // namespace ge2e

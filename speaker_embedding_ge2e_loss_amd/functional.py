@@ -109,13 +109,46 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
     return out
 
 
-def cos_sim(embeddings: torch.Tensor, *, eps: float = SMALL_ERR, eps_cos: float = EPS_COS) -> torch.Tensor:
-    """get_cos_sim (s3:42-80) forward: (N,M,D) -> (N,M,N) or batched."""
+_warned_forward_only = set()
+
+
+def _forward_only(name: str, *tensors):
+    """The static helpers have no backward here (training goes through GE2ELoss.forward / ge2e_loss, which
+    produces dE, dw, db in the same launch).  The reference's own eval script (s5:36-44) calls them on
+    graph-attached embeddings and detaches the result, so this cannot be an error; but a result silently
+    cut off from the graph would train nothing, so the first such call per helper warns."""
+    if name not in _warned_forward_only and torch.is_grad_enabled() and \
+            any(t is not None and t.requires_grad for t in tensors):
+        _warned_forward_only.add(name)
+        import warnings
+        warnings.warn(f"{name} is forward-only in this implementation (its result carries no grad_fn); "
+                      "use GE2ELoss.forward / ge2e_loss for the differentiable path", RuntimeWarning, stacklevel=3)
+
+
+def cos_sim(embeddings: torch.Tensor, centroids: torch.Tensor | None = None, *, eps: float = SMALL_ERR,
+            eps_cos: float = EPS_COS) -> torch.Tensor:
+    """get_cos_sim (s3:42-80) forward: (N,M,D) [, centroids (N,D)] -> (N,M,N) or batched.
+
+    With ``centroids`` the other-speaker columns use them (as the reference does with its second
+    argument); without, they are get_centroids(embeddings) -- what every caller in the reference passes.
+    """
     lib = _lib.load()
     _require_cuda(embeddings, "embeddings")
+    _forward_only("get_cos_sim", embeddings, centroids)
     e4, squeeze = _as_batched(embeddings)
     B, N, M, D = e4.shape
     cos = torch.empty(B, N, M, N, dtype=torch.float32, device=e4.device)
+    if centroids is not None:
+        _require_cuda(centroids, "centroids")
+        c3 = centroids.detach().to(torch.float32).reshape(B, -1, D).contiguous()
+        if c3.shape[1] != N:
+            # s3:77-78 indexes cos_diff[j, :, j] for every speaker j: the reference needs as many centroids as speakers
+            raise RuntimeError(f"get_cos_sim: {c3.shape[1]} centroids for {N} speakers")
+        with torch.cuda.device(e4.device):
+            code = lib.ge2e_cos_sim_centroids(e4.data_ptr(), c3.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(),
+                                              _stream_ptr(e4))
+        _lib.check(code, "ge2e_cos_sim_centroids")
+        return cos[0] if squeeze else cos
     ws = alloc_workspace(lib.ge2e_workspace_bytes(B, N, M, D, 0, _lib.IMPL_GENERIC), e4.device)
     with torch.cuda.device(e4.device):
         code = lib.ge2e_cos_sim(e4.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(),
@@ -128,6 +161,7 @@ def centroids(embeddings: torch.Tensor) -> torch.Tensor:
     """get_centroids (s3:34-38) forward: mean over the utterance axis."""
     lib = _lib.load()
     _require_cuda(embeddings, "embeddings")
+    _forward_only("get_centroids", embeddings)
     e4, squeeze = _as_batched(embeddings)
     B, N, M, D = e4.shape
     cent = torch.empty(B, N, D, dtype=torch.float32, device=e4.device)
@@ -141,6 +175,7 @@ def calc_loss(sim_matrix: torch.Tensor, *, eps: float = SMALL_ERR, variant: str 
     """calc_loss (s3:115-127) forward on a (N,M,N) or (B,N,M,N) similarity matrix."""
     lib = _lib.load()
     _require_cuda(sim_matrix, "sim_matrix")
+    _forward_only("calc_loss", sim_matrix)
     s = sim_matrix
     squeeze = s.dim() == 3
     if squeeze:

@@ -58,10 +58,9 @@ class GE2ELoss(nn.Module):
     # eq. (5) cosines -- s3:41-80 (forward only here; the training path is forward())
     @staticmethod
     def get_cos_sim(embeddings, centroids, hp):
-        # `centroids` is accepted for signature parity; the kernel recomputes them from
-        # `embeddings` exactly as get_centroids does (s3:23 always passes that value).
-        del centroids
-        return GF.cos_sim(embeddings, eps=hp.general.small_err)
+        # like the reference: `centroids` feeds every other-speaker column, the own-speaker column uses the
+        # leave-one-out centroid of `embeddings` (s3:44-57, 64-78)
+        return GF.cos_sim(embeddings, centroids, eps=hp.general.small_err)
 
     # eq. (8) -- s3:83-93, dead code in the reference (no caller); kept as an API stub
     @staticmethod

