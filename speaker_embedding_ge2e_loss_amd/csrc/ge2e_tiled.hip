@@ -61,6 +61,101 @@ __device__ __forceinline__ Tiles carve_tiles(_Float16* base) {
     return Tiles{base, base + 64 * TP, base + 2 * 64 * TP, base + 3 * 64 * TP};
 }
 
+
+// ---- 128 x 128 x 64 tile contraction, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles -------------------
+// One LDS stage (73.7 KB -> two workgroups per CU) + register prefetch: the global loads of K-step s + 1 are in
+// flight while the 48 MFMAs per wave of K-step s issue.  An operand is either "K-contiguous" (global [row][K],
+// LDS [128][KP], fragments by ds_read_b128) or "K-rows" (global [K][col], LDS [64][RP], fragments by the
+// transposing read); both pitches put consecutive rows 8 banks apart (conflict-free for either read).
+constexpr int KP = 72;    // K-contiguous tile pitch (halfs): 64 + 8
+constexpr int RP = 144;   // K-rows tile pitch (halfs): 128 + 16
+constexpr int PLANE = 128 * KP;   // = 64 * RP halfs per plane
+constexpr size_t GEMM_LDS_BYTES = (size_t)4 * PLANE * sizeof(_Float16);
+
+struct Opnd {
+    const _Float16* hi;   // plane pointers already offset to the tile's first row (K-contig) / first column (K-rows)
+    const _Float16* lo;
+    size_t ld;            // leading dimension of the global image (halfs)
+    int valid;            // K-contig: valid tile rows; K-rows: valid tile columns
+};
+
+template <bool KC>
+__device__ __forceinline__ void gemm_fetch(const Opnd& o, int k0, int kvalid, int tid, uint4 (&rh)[4], uint4 (&rl)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+        if (KC) {   // tile [128 rows][64 K]
+            const int row = idx >> 3, c8 = (idx & 7) * 8;
+            if (row < o.valid && c8 < kvalid) {
+                vh = *reinterpret_cast<const uint4*>(o.hi + (size_t)row * o.ld + k0 + c8);
+                vl = *reinterpret_cast<const uint4*>(o.lo + (size_t)row * o.ld + k0 + c8);
+            }
+        } else {    // tile [64 K-rows][128 cols]
+            const int row = idx >> 4, c8 = (idx & 15) * 8;
+            if (row < kvalid && c8 < o.valid) {
+                vh = *reinterpret_cast<const uint4*>(o.hi + (size_t)(k0 + row) * o.ld + c8);
+                vl = *reinterpret_cast<const uint4*>(o.lo + (size_t)(k0 + row) * o.ld + c8);
+            }
+        }
+        rh[i] = vh; rl[i] = vl;
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void gemm_stash(_Float16* th, _Float16* tl, int tid, const uint4 (&rh)[4], const uint4 (&rl)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int off = KC ? (idx >> 3) * KP + (idx & 7) * 8 : (idx >> 4) * RP + (idx & 15) * 8;
+        *reinterpret_cast<uint4*>(th + off) = rh[i];
+        *reinterpret_cast<uint4*>(tl + off) = rl[i];
+    }
+}
+template <bool KC>
+__device__ __forceinline__ h8 gemm_frag(const _Float16* t, int blk0, int s, int lane) {
+    if (KC) return frag_row(t + (blk0 + (lane & 31)) * KP + 8 * (lane >> 5) + 16 * s);
+    return frag_tr(t, RP, 16 * s, blk0, lane);
+}
+
+// acc[a2][b2] += A[64 wa + 32 a2 ..][K] . B[64 wb + 32 b2 ..][K]  over K = [0, ktotal)
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void gemm128(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
+                                        f32x16 (&acc)[2][2]) {
+    _Float16* const Ah = sm;
+    _Float16* const Al = sm + PLANE;
+    _Float16* const Bh = sm + 2 * PLANE;
+    _Float16* const Bl = sm + 3 * PLANE;
+    const int lane = tid & 63, wid = tid >> 6, wa = wid >> 1, wb = wid & 1;
+    uint4 pah[4], pal[4], pbh[4], pbl[4];
+    gemm_fetch<AKC>(A, 0, min(64, ktotal), tid, pah, pal);
+    gemm_fetch<BKC>(B, 0, min(64, ktotal), tid, pbh, pbl);
+    for (int k0 = 0; k0 < ktotal; k0 += 64) {
+        gemm_stash<AKC>(Ah, Al, tid, pah, pal);
+        gemm_stash<BKC>(Bh, Bl, tid, pbh, pbl);
+        __syncthreads();
+        if (k0 + 64 < ktotal) {   // next K-step's operands: in flight under the MFMAs below
+            gemm_fetch<AKC>(A, k0 + 64, min(64, ktotal - k0 - 64), tid, pah, pal);
+            gemm_fetch<BKC>(B, k0 + 64, min(64, ktotal - k0 - 64), tid, pbh, pbl);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ah[u] = gemm_frag<AKC>(Ah, 64 * wa + 32 * u, s, lane);
+                al[u] = gemm_frag<AKC>(Al, 64 * wa + 32 * u, s, lane);
+                bh[u] = gemm_frag<BKC>(Bh, 64 * wb + 32 * u, s, lane);
+                bl[u] = gemm_frag<BKC>(Bl, 64 * wb + 32 * u, s, lane);
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) acc[a2][b2] = mfma3(ah[a2], al[a2], bh[b2], bl[b2], acc[a2][b2]);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -149,48 +244,45 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per 64 x 64 tile, 4 waves as 2 x 2.
-__global__ __launch_bounds__(256) void ge2e_tiled_sim(Problem p, TiledWs L) {
-    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
-    const Tiles T = carve_tiles(sm);
+// k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per 128 x 128 tile (gemm128, both operands K-contiguous).
+__global__ __launch_bounds__(256, 2) void ge2e_tiled_sim(Problem p, TiledWs L) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M;
-    const int rt = L.row_tiles, ct = L.cen_tiles;
+    const int rt = (NM + 127) / 128, ct = (N + 127) / 128;
     int t = blockIdx.x;
     const int kt = t % ct; t /= ct;
     const int rtile = t % rt;
     const int bi = t / rt;
     const size_t NMp = (size_t)NM;
-    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * 64 * D;
-    const _Float16* EHl = EHh + NMp * D;
-    const _Float16* CHh = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * 64 * D;
-    const _Float16* CHl = CHh + (size_t)N * D;
-    const int rows_a = min(64, NM - rtile * 64), rows_b = min(64, N - kt * 64);
-    const int a = wid >> 1, b = wid & 1;
-    f32x16 acc;
+    Opnd A, Bo;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * 128 * D;
+    A.lo = A.hi + NMp * D;
+    A.ld = D; A.valid = min(128, NM - rtile * 128);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * 128 * D;
+    Bo.lo = Bo.hi + (size_t)N * D;
+    Bo.ld = D; Bo.valid = min(128, N - kt * 128);
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int kc = 0; kc < D; kc += 64) {
-        stage_tile(EHh + kc, D, rows_a, T.Ah, tid);
-        stage_tile(EHl + kc, D, rows_a, T.Al, tid);
-        stage_tile(CHh + kc, D, rows_b, T.Bh, tid);
-        stage_tile(CHl + kc, D, rows_b, T.Bl, tid);
-        __syncthreads();
-        const int oa = (32 * a + (lane & 31)) * TP + 8 * (lane >> 5);
-        const int ob = (32 * b + (lane & 31)) * TP + 8 * (lane >> 5);
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = mfma3(frag_row(T.Ah + oa + 16 * s), frag_row(T.Al + oa + 16 * s),
-                        frag_row(T.Bh + ob + 16 * s), frag_row(T.Bl + ob + 16 * s), acc);
-        __syncthreads();
-    }
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+    gemm128<true, true>(A, Bo, D, gsm, tid, acc);
     float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
-    const int l31 = lane & 31, h = lane >> 5;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = rtile * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (r < NM) X[(size_t)r * L.npad + kt * 64 + 32 * b + l31] = acc[i] * kSplitInv2;
-    }
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int k = kt * 128 + 64 * wb + 32 * b2 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = rtile * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (r < NM && k < L.npad) X[(size_t)r * L.npad + k] = acc[a2][b2][i] * kSplitInv2;
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,46 +389,45 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (64 centroids x 64 d) tile,
-// looping over all row tiles of the batch; both operands through the transposing load.
-__global__ __launch_bounds__(256) void ge2e_tiled_gc(Problem p, TiledWs L) {
-    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
-    const Tiles T = carve_tiles(sm);
+// k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (128 centroids x 128 d) tile over all rows of the
+// batch (gemm128, both operands with K along their rows -> transposing reads).
+__global__ __launch_bounds__(256, 2) void ge2e_tiled_gc(Problem p, TiledWs L) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M, npad = L.npad;
-    const int dtiles = D >> 6, ct = L.cen_tiles;
+    const int dtiles = (D + 127) / 128, ct = (N + 127) / 128;
     int t = blockIdx.x;
     const int dt = t % dtiles; t /= dtiles;
     const int kt = t % ct;
     const int bi = t / ct;
-    const _Float16* GHh = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * 64;
-    const _Float16* GHl = GHh + (size_t)NM * npad;
-    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * 64;
-    const _Float16* EHl = EHh + (size_t)NM * D;
-    const int a = wid >> 1, b = wid & 1;
-    f32x16 acc;
+    Opnd A, Bo;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * 128;
+    A.lo = A.hi + (size_t)NM * npad;
+    A.ld = npad; A.valid = min(128, npad - kt * 128);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * 128;
+    Bo.lo = Bo.hi + (size_t)NM * D;
+    Bo.ld = D; Bo.valid = min(128, D - dt * 128);
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int r0 = 0; r0 < NM; r0 += 64) {
-        const int rows = min(64, NM - r0);
-        stage_tile(GHh + (size_t)r0 * npad, npad, rows, T.Ah, tid);
-        stage_tile(GHl + (size_t)r0 * npad, npad, rows, T.Al, tid);
-        stage_tile(EHh + (size_t)r0 * D, D, rows, T.Bh, tid);
-        stage_tile(EHl + (size_t)r0 * D, D, rows, T.Bl, tid);
-        __syncthreads();
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = mfma3(frag_tr(T.Ah, TP, 16 * s, 32 * a, lane), frag_tr(T.Al, TP, 16 * s, 32 * a, lane),
-                        frag_tr(T.Bh, TP, 16 * s, 32 * b, lane), frag_tr(T.Bl, TP, 16 * s, 32 * b, lane), acc);
-        __syncthreads();
-    }
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+    gemm128<false, false>(A, Bo, NM, gsm, tid, acc);
     float* GC = p.ws + L.gc + (size_t)bi * N * D;
-    const int l31 = lane & 31, h = lane >> 5;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = kt * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (k < N) GC[(size_t)k * D + dt * 64 + 32 * b + l31] = acc[i] * kSplitInv2;
-    }
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int d = dt * 128 + 64 * wb + 32 * b2 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = kt * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (k < N && d < D) GC[(size_t)k * D + d] = acc[a2][b2][i] * kSplitInv2;
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -392,57 +483,55 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (64 rows x 64 d) tile, then the epilogue.
-__global__ __launch_bounds__(256) void ge2e_tiled_ge(Problem p, TiledWs L) {
-    __shared__ __attribute__((aligned(16))) _Float16 sm[4 * 64 * TP];
-    const Tiles T = carve_tiles(sm);
+// k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (128 rows x 128 d) tile (gemm128: A K-contiguous, B K-rows), then the
+// epilogue dE = ra gE + c1e e + rc c-hat_j + KJ_j.
+__global__ __launch_bounds__(256, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
-    const int dtiles = D >> 6, rt = L.row_tiles;
+    const int dtiles = (D + 127) / 128, rt = (NM + 127) / 128;
     int t = blockIdx.x;
     const int dt = t % dtiles; t /= dtiles;
     const int rtile = t % rt;
     const int bi = t / rt;
-    const _Float16* GHh = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * 64 * npad;
-    const _Float16* GHl = GHh + (size_t)NM * npad;
-    const _Float16* CHh = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * 64;
-    const _Float16* CHl = CHh + (size_t)N * D;
-    const int rows_a = min(64, NM - rtile * 64);
-    const int a = wid >> 1, b = wid & 1;
-    f32x16 acc;
+    Opnd A, Bo;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * 128 * npad;
+    A.lo = A.hi + (size_t)NM * npad;
+    A.ld = npad; A.valid = min(128, NM - rtile * 128);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * 128;
+    Bo.lo = Bo.hi + (size_t)N * D;
+    Bo.ld = D; Bo.valid = min(128, D - dt * 128);
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < npad; k0 += 64) {
-        const int rows_b = min(64, N - k0);
-        stage_tile(GHh + k0, npad, rows_a, T.Ah, tid);
-        stage_tile(GHl + k0, npad, rows_a, T.Al, tid);
-        stage_tile(CHh + (size_t)k0 * D, D, rows_b, T.Bh, tid);
-        stage_tile(CHl + (size_t)k0 * D, D, rows_b, T.Bl, tid);
-        __syncthreads();
-        const int oa = (32 * a + (lane & 31)) * TP + 8 * (lane >> 5);
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = mfma3(frag_row(T.Ah + oa + 16 * s), frag_row(T.Al + oa + 16 * s),
-                        frag_tr(T.Bh, TP, 16 * s, 32 * b, lane), frag_tr(T.Bl, TP, 16 * s, 32 * b, lane), acc);
-        __syncthreads();
-    }
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+    gemm128<true, false>(A, Bo, N, gsm, tid, acc);   // K = the N real centroid slots (pad columns of GH are zero)
     const float* E = p.E + (size_t)bi * NM * D;
     float* dE = p.dE + (size_t)bi * NM * D;
     const float* CHf = p.ws + L.chf + (size_t)bi * N * D;
     const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
     const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int d = dt * 64 + 32 * b + l31;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = rtile * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (r < NM) {
-            const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)r * 8);  // ra c1e c2s c3
-            const int j = r / M;
-            dE[(size_t)r * D + d] = acc[i] * rs.x + E[(size_t)r * D + d] * rs.y + CHf[(size_t)j * D + d] * rs.z +
-                                    KJ[(size_t)j * D + d];
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = rtile * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (r < NM) {
+                const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)r * 8);  // ra c1e c2s c3
+                const int j = r / M;
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int d = dt * 128 + 64 * wb + 32 * b2 + l31;
+                    if (d < D)
+                        dE[(size_t)r * D + d] = acc[a2][b2][i] * rs.x + E[(size_t)r * D + d] * rs.y +
+                                                CHf[(size_t)j * D + d] * rs.z + KJ[(size_t)j * D + d];
+                }
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,13 +589,23 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const int NM = p.N * p.M;
     const unsigned spk_blocks = (unsigned)((p.B * p.N + 3) / 4);
     const unsigned row_blocks = (unsigned)(((size_t)p.B * NM + 3) / 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        for (const void* fn : {reinterpret_cast<const void*>(ge2e_tiled_sim), reinterpret_cast<const void*>(ge2e_tiled_gc),
+                               reinterpret_cast<const void*>(ge2e_tiled_ge)}) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_done = true;
+    }
+    const unsigned rt128 = (unsigned)((NM + 127) / 128), ct128 = (unsigned)((p.N + 127) / 128), dt128 = (unsigned)((p.D + 127) / 128);
     hipLaunchKernelGGL(ge2e_tiled_prep, dim3(spk_blocks), dim3(256), 0, stream, p, L);
-    hipLaunchKernelGGL(ge2e_tiled_sim, dim3((unsigned)(p.B * L.row_tiles * L.cen_tiles)), dim3(256), 0, stream, p, L);
+    hipLaunchKernelGGL(ge2e_tiled_sim, dim3((unsigned)p.B * rt128 * ct128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
     hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
     if (p.dE) {
-        hipLaunchKernelGGL(ge2e_tiled_gc, dim3((unsigned)(p.B * L.cen_tiles * (p.D / 64))), dim3(256), 0, stream, p, L);
+        hipLaunchKernelGGL(ge2e_tiled_gc, dim3((unsigned)p.B * ct128 * dt128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
         hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
-        hipLaunchKernelGGL(ge2e_tiled_ge, dim3((unsigned)(p.B * L.row_tiles * (p.D / 64))), dim3(256), 0, stream, p, L);
+        hipLaunchKernelGGL(ge2e_tiled_ge, dim3((unsigned)p.B * rt128 * dt128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
     }
     hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
     return hipGetLastError();
