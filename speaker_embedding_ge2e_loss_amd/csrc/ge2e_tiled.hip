@@ -271,16 +271,20 @@ __global__ __launch_bounds__(256, 2) void ge2e_tiled_sim(Problem p, TiledWs L) {
             for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
     gemm128<true, true>(A, Bo, D, gsm, tid, acc);
     float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-            const int k = kt * 128 + 64 * wb + 32 * b2 + l31;
+        for (int g = 0; g < 4; ++g) {
+            const int r = rtile * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = rtile * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (r < NM && k < L.npad) X[(size_t)r * L.npad + k] = acc[a2][b2][i] * kSplitInv2;
+            for (int b2 = 0; b2 < 2; ++b2) {
+                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                quad_transpose4(x, lane);
+                const int k = kt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                if (r < NM && k < L.npad)
+                    *reinterpret_cast<float4*>(X + (size_t)r * L.npad + k) =
+                        make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
             }
         }
 }
@@ -416,16 +420,20 @@ __global__ __launch_bounds__(256, 2) void ge2e_tiled_gc(Problem p, TiledWs L) {
             for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
     gemm128<false, false>(A, Bo, NM, gsm, tid, acc);
     float* GC = p.ws + L.gc + (size_t)bi * N * D;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-            const int d = dt * 128 + 64 * wb + 32 * b2 + l31;
+        for (int g = 0; g < 4; ++g) {
+            const int k = kt * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k = kt * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (k < N && d < D) GC[(size_t)k * D + d] = acc[a2][b2][i] * kSplitInv2;
+            for (int b2 = 0; b2 < 2; ++b2) {
+                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                quad_transpose4(x, lane);
+                const int d = dt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                if (k < N && d < D)
+                    *reinterpret_cast<float4*>(GC + (size_t)k * D + d) =
+                        make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
             }
         }
 }
@@ -514,21 +522,30 @@ __global__ __launch_bounds__(256, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
     const float* CHf = p.ws + L.chf + (size_t)bi * N * D;
     const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
     const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1;
+    // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
+    // columns: every global access of the epilogue is 16 bytes wide (8 rows x 128 B per wave-instruction)
+    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = rtile * 128 + 64 * wa + 32 * a2 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (r < NM) {
-                const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)r * 8);  // ra c1e c2s c3
-                const int j = r / M;
+        for (int g = 0; g < 4; ++g) {
+            const int r = rtile * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
+            const bool rv = r < NM;
+            const int rc = rv ? r : NM - 1;
+            const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)rc * 8);  // ra c1e c2s c3
+            const int j = rc / M;
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    const int d = dt * 128 + 64 * wb + 32 * b2 + l31;
-                    if (d < D)
-                        dE[(size_t)r * D + d] = acc[a2][b2][i] * rs.x + E[(size_t)r * D + d] * rs.y +
-                                                CHf[(size_t)j * D + d] * rs.z + KJ[(size_t)j * D + d];
+            for (int b2 = 0; b2 < 2; ++b2) {
+                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                quad_transpose4(x, lane);
+                const int d = dt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                if (rv && d < D) {
+                    const float4 e = *reinterpret_cast<const float4*>(E + (size_t)r * D + d);
+                    const float4 c = *reinterpret_cast<const float4*>(CHf + (size_t)j * D + d);
+                    const float4 kj = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + d);
+                    *reinterpret_cast<float4*>(dE + (size_t)r * D + d) =
+                        make_float4(x[0] * rs.x + e.x * rs.y + c.x * rs.z + kj.x, x[1] * rs.x + e.y * rs.y + c.y * rs.z + kj.y,
+                                    x[2] * rs.x + e.z * rs.y + c.z * rs.z + kj.z, x[3] * rs.x + e.w * rs.y + c.w * rs.z + kj.w);
                 }
             }
         }
