@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void ge2e_tiled_sim(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rows: one wave per row; the row of X (<= 1024 centroids) lives in 16 registers per lane.
+// k_rows: one wave per row; the row of X (<= 1024 centroids) lives in 16 registers per lane (4 x 4 consecutive slots).
 __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
     const int lane = threadIdx.x & 63;
     const size_t gr = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // global row
@@ -312,20 +312,25 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
     unit_stats_fast(uu, p.eps_cos, rnu, ku);
     const float cosd = eu * rne * rnu;
     const float sjj = w * (cosd + eps) + bias;
-    const int nch = npad >> 6;
-    float c0[16], g[16];
+    // lane l holds the 4 consecutive centroid slots 256 c + 4 l .. + 3 of up to four 256-slot chunks: 16-byte reads
+    // of X and 8-byte writes of the two G planes (2-byte stores cost ~12x per byte)
+    float c0[4][4], g[4][4];
     float mx = -INFINITY, best = -INFINITY;
     int besti = 0x7fffffff;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        c0[c] = 0.f;
-        if (c < nch) {
-            const int k = 64 * c + lane;
-            c0[c] = (k == j) ? cosd : X[k];
+    for (int c = 0; c < 4; ++c) {
+        const int kb = 256 * c + 4 * lane;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb < npad) xv = *reinterpret_cast<const float4*>(X + kb);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = kb + e;
+            c0[c][e] = (k == j) ? cosd : xe[e];
             if (k < N) {
-                const float s = w * (c0[c] + eps) + bias;
-                mx = fmaxf(mx, s);
-                if (k != j && s > best) { best = s; besti = k; }
+                const float sv = w * (c0[c][e] + eps) + bias;
+                mx = fmaxf(mx, sv);
+                if (k != j && sv > best) { best = sv; besti = k; }
             }
         }
     }
@@ -334,47 +339,55 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
         mx = fmaxf(wave_max(mx), log_eps);
         float zoff = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int k = 64 * c + lane;
-            g[c] = (c < nch && k < N) ? __expf(w * (c0[c] + eps) + bias - mx) : 0.f;
-            if (k != j) zoff += g[c];
-        }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 256 * c + 4 * lane + e;
+                g[c][e] = (k < N) ? __expf(w * (c0[c][e] + eps) + bias - mx) : 0.f;
+                if (k != j) zoff += g[c][e];
+            }
         zoff = wave_sum(zoff) + __expf(log_eps - mx);
         const float z = zoff + __expf(sjj - mx);
         per = (mx - sjj) + __logf(z);
         const float rz = 1.0f / z;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) g[c] = (64 * c + lane == j) ? -zoff * rz : g[c] * rz;
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[c][e] = (256 * c + 4 * lane + e == j) ? -zoff * rz : g[c][e] * rz;
     } else {
         wave_argmax(best, besti);
         const float pos = 1.0f / (1.0f + __expf(-sjj));
         const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
         per = 1.0f - pos + neg;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int k = 64 * c + lane;
-            g[c] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
-        }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 256 * c + 4 * lane + e;
+                g[c][e] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+            }
     }
     float dwv = 0.f, dbv = 0.f, coef = 0.f, ad = 0.f;
     _Float16* GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r * npad;
     _Float16* GHl = GHh + (size_t)NM * npad;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        if (c < nch) {
-            const int k = 64 * c + lane;
-            float gv = (k < N) ? g[c] : 0.f;
-            dwv += gv * (c0[c] + eps);
-            dbv += gv;
-            coef += gv * c0[c];
-            if (k == j) { ad = gv; gv = 0.f; }
-            const float x = gv * kSplitScale;
-            const _Float16 hi = (_Float16)x;
-            unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, hi);
-            asm volatile("" : "+v"(hb));  // residual against the stored bits (see split4)
-            const _Float16 hi2 = __builtin_bit_cast(_Float16, (unsigned short)hb);
-            GHh[k] = hi2;
-            GHl[k] = (_Float16)(x - (float)hi2);
+    for (int c = 0; c < 4; ++c) {
+        const int kb = 256 * c + 4 * lane;
+        if (kb < npad) {
+            float gv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kb + e;
+                gv[e] = (k < N) ? g[c][e] : 0.f;
+                dwv += gv[e] * (c0[c][e] + eps);
+                dbv += gv[e];
+                coef += gv[e] * c0[c][e];
+                if (k == j) { ad = gv[e]; gv[e] = 0.f; }
+            }
+            h4 hi, lo;
+            split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
+            *reinterpret_cast<h4*>(GHh + kb) = hi;
+            *reinterpret_cast<h4*>(GHl + kb) = lo;
         }
     }
     dwv = wave_sum(dwv); dbv = wave_sum(dbv);
