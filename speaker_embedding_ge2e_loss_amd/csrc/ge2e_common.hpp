@@ -132,6 +132,11 @@ __device__ __forceinline__ void oct_argmax(float& v, int& i) {
     quad_argmax(v, i);
     argmax_merge(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));
 }
+__device__ __forceinline__ void row16_argmax(float& v, int& i) {
+    quad_argmax(v, i);
+    argmax_merge(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));
+    argmax_merge(v, i, dpp_f<DPP_MIRROR>(v), dpp_i<DPP_MIRROR>(i));
+}
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     quad_argmax(v, i);
     argmax_merge(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));

@@ -405,6 +405,124 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
     }
 }
 
+// k_rows for N <= 256: 16 lanes per row, 4 rows per wave (a wave per row is latency-bound: one short dependent chain
+// per wave and 655 k waves per launch at cfg4).  Lane l of a row holds the slots 64 c + 4 l .. + 3 of up to four chunks.
+__global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
+    const int l16 = threadIdx.x & 15;
+    const size_t gr_ = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // global row
+    const int N = p.N, M = p.M, NM = N * M, npad = L.npad;
+    const size_t rows_total = (size_t)p.B * NM;
+    const bool live = gr_ < rows_total;
+    const size_t gr = live ? gr_ : rows_total - 1;      // dead rows recompute the last row and store nothing
+    const int bi = (int)(gr / NM), r = (int)(gr - (size_t)bi * NM), j = r / M;
+    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    const float eps = p.eps, log_eps = p.log_eps;
+    const float inv_m1 = 1.0f / (float)(M - 1);
+    const float* X = p.ws + L.x + ((size_t)bi * NM + r) * npad;
+    const float4 rst = *reinterpret_cast<const float4*>(p.ws + L.rst + gr * 4);      // rne ke ee
+    const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);  // rn kap |s| |s|^2
+    const float rne = rst.x, ke = rst.y, ee = rst.z;
+    const float xo = X[j];
+    const float es = xo * cs.z / rne;
+    const float eu = (es - ee) * inv_m1;
+    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+    float rnu, ku;
+    unit_stats_fast(uu, p.eps_cos, rnu, ku);
+    const float cosd = eu * rne * rnu;
+    const float sjj = w * (cosd + eps) + bias;
+    float c0[4][4], g[4][4];
+    float mx = -INFINITY, best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int kb = 64 * c + 4 * l16;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb < npad) xv = *reinterpret_cast<const float4*>(X + kb);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = kb + e;
+            c0[c][e] = (k == j) ? cosd : xe[e];
+            if (k < N) {
+                const float sv = w * (c0[c][e] + eps) + bias;
+                mx = fmaxf(mx, sv);
+                if (k != j && sv > best) { best = sv; besti = k; }
+            }
+        }
+    }
+    float per;
+    if (p.variant == 0) {
+        mx = fmaxf(row16_max(mx), log_eps);
+        float zoff = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 64 * c + 4 * l16 + e;
+                g[c][e] = (k < N) ? __expf(w * (c0[c][e] + eps) + bias - mx) : 0.f;
+                if (k != j) zoff += g[c][e];
+            }
+        zoff = row16_sum(zoff) + __expf(log_eps - mx);
+        const float z = zoff + __expf(sjj - mx);
+        per = (mx - sjj) + __logf(z);
+        const float rz = 1.0f / z;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[c][e] = (64 * c + 4 * l16 + e == j) ? -zoff * rz : g[c][e] * rz;
+    } else {
+        row16_argmax(best, besti);
+        const float pos = 1.0f / (1.0f + __expf(-sjj));
+        const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
+        per = 1.0f - pos + neg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 64 * c + 4 * l16 + e;
+                g[c][e] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+            }
+    }
+    float dwv = 0.f, dbv = 0.f, coef = 0.f, ad = 0.f;
+    _Float16* GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r * npad;
+    _Float16* GHl = GHh + (size_t)NM * npad;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int kb = 64 * c + 4 * l16;
+        if (kb < npad) {
+            float gv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kb + e;
+                gv[e] = (k < N) ? g[c][e] : 0.f;
+                dwv += gv[e] * (c0[c][e] + eps);
+                dbv += gv[e];
+                coef += gv[e] * c0[c][e];
+                if (k == j) { ad = gv[e]; gv[e] = 0.f; }
+            }
+            h4 hi, lo;
+            split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
+            if (live) {
+                *reinterpret_cast<h4*>(GHh + kb) = hi;
+                *reinterpret_cast<h4*>(GHl + kb) = lo;
+            }
+        }
+    }
+    dwv = row16_sum(dwv); dbv = row16_sum(dbv);
+    coef = w * row16_sum(coef); ad = w * row16_sum(ad);
+    if (l16 == 0 && live) {
+        const float rho = rnu * inv_m1;
+        const float c2 = rho * (ad * rne + ad * ku * cosd * rnu * inv_m1);
+        const float c1 = (-ke * coef * rne - ad * rnu * inv_m1) - c2 / rne;
+        const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne);
+        const float beta = -ad * rnu * ku * cosd * rho;
+        float* rs = p.ws + L.rs + gr * 8;
+        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, c2 * cs.z, alpha * inv_m1);
+        *reinterpret_cast<float4*>(rs + 4) = make_float4(beta * inv_m1, per, dwv, dbv);
+        if (p.per) p.per[gr] = per;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (128 centroids x 128 d) tile over all rows of the
 // batch (gemm128, both operands with K along their rows -> transposing reads).
@@ -631,7 +749,10 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const unsigned rt128 = (unsigned)((NM + 127) / 128), ct128 = (unsigned)((p.N + 127) / 128), dt128 = (unsigned)((p.D + 127) / 128);
     hipLaunchKernelGGL(ge2e_tiled_prep, dim3(spk_blocks), dim3(256), 0, stream, p, L);
     hipLaunchKernelGGL(ge2e_tiled_sim, dim3((unsigned)p.B * rt128 * ct128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
-    hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
+    if (L.npad <= 256)
+        hipLaunchKernelGGL(ge2e_tiled_rows16, dim3((unsigned)(((size_t)p.B * NM + 15) / 16)), dim3(256), 0, stream, p, L);
+    else
+        hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
     if (p.dE) {
         hipLaunchKernelGGL(ge2e_tiled_gc, dim3((unsigned)p.B * ct128 * dt128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
         hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
