@@ -62,15 +62,28 @@ __device__ __forceinline__ Tiles carve_tiles(_Float16* base) {
 }
 
 
-// ---- 128 x 128 x 64 tile contraction, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles -------------------
-// One LDS stage (73.7 KB -> two workgroups per CU) + register prefetch: the global loads of K-step s + 1 are in
-// flight while the 48 MFMAs per wave of K-step s issue.  An operand is either "K-contiguous" (global [row][K],
-// LDS [128][KP], fragments by ds_read_b128) or "K-rows" (global [K][col], LDS [64][RP], fragments by the
-// transposing read); both pitches put consecutive rows 8 banks apart (conflict-free for either read).
-constexpr int KP = 72;    // K-contiguous tile pitch (halfs): 64 + 8
-constexpr int RP = 144;   // K-rows tile pitch (halfs): 128 + 16
-constexpr int PLANE = 128 * KP;   // = 64 * RP halfs per plane
-constexpr size_t GEMM_LDS_BYTES = (size_t)4 * PLANE * sizeof(_Float16);
+// ---- tile contraction TM x TN x 64 on the split-fp16 MFMA (one LDS stage + register prefetch) ----------------------
+// Two shapes: <128,128> = 4 waves as 2 x 2, each 64 x 64 (74 KB of LDS -> two workgroups per CU), and <256,256> =
+// 8 waves as 2 x 4, each 128 x 64 (147 KB, one workgroup per CU).  A 64 x 64 wave tile re-reads 682 B of fragments
+// per MFMA (8 waves ask ~170 B/clk of a 128 B/clk LDS); 128 x 64 needs 512 B and the 256 x 256 stage halves the LDS
+// WRITE bytes per MFMA, which cost 3-4x a read -- the big shape is for contractions with both extents >= 256.
+// The global loads of K-step s + 1 are in flight while the MFMAs of K-step s issue.  An operand is either
+// "K-contiguous" (global [row][K], LDS [T][KS + 8], fragments by ds_read_b128) or "K-rows" (global [K][col],
+// LDS [KS][T + 16], fragments by the transposing read); KS = 64 (small tile) or 32 (big tile: its prefetch must fit
+// in registers next to 128 accumulator VGPRs).
+template <int TM_, int TN_>
+struct GemmCfg {
+    static constexpr int TM = TM_, TN = TN_;
+    static constexpr int NT = TM_ == 256 ? 512 : 256;              // threads
+    static constexpr int WN = TM_ == 256 ? 4 : 2;                  // waves along N (2 along M)
+    static constexpr int A2 = TM_ / 64, B2 = TN_ / (32 * WN);      // 32-row / 32-column blocks per wave
+    static constexpr int KS = TM_ == 256 ? 32 : 64;                // K per stage (the big tile's prefetch must fit in registers)
+    static constexpr int KP = KS + 8;                              // K-contiguous tile pitch (halfs)
+    static constexpr int NP = KS / 16;                             // 16-byte pieces per plane per thread (= T * KS / 8 / NT)
+    static constexpr int PLANE_A = TM_ * KP > KS * (TM_ + 16) ? TM_ * KP : KS * (TM_ + 16);
+    static constexpr int PLANE_B = TN_ * KP > KS * (TN_ + 16) ? TN_ * KP : KS * (TN_ + 16);
+    static constexpr size_t LDS_BYTES = (size_t)2 * (PLANE_A + PLANE_B) * sizeof(_Float16);
+};
 
 struct Opnd {
     const _Float16* hi;   // plane pointers already offset to the tile's first row (K-contig) / first column (K-rows)
@@ -79,20 +92,22 @@ struct Opnd {
     int valid;            // K-contig: valid tile rows; K-rows: valid tile columns
 };
 
-template <bool KC>
-__device__ __forceinline__ void gemm_fetch(const Opnd& o, int k0, int kvalid, int tid, uint4 (&rh)[4], uint4 (&rl)[4]) {
+// T = tile extent of this operand (rows if K-contiguous, columns if K-rows)
+template <class C, bool KC, int T>
+__device__ __forceinline__ void gemm_fetch(const Opnd& o, int k0, int kvalid, int tid, uint4 (&rh)[C::NP], uint4 (&rl)[C::NP]) {
+    static_assert(T * (C::KS / 8) == C::NP * C::NT, "pieces per plane per thread");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
+    for (int i = 0; i < C::NP; ++i) {
+        const int idx = tid + C::NT * i;
         uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-        if (KC) {   // tile [128 rows][64 K]
-            const int row = idx >> 3, c8 = (idx & 7) * 8;
+        if (KC) {   // tile [T rows][KS K]
+            const int row = idx / (C::KS / 8), c8 = (idx % (C::KS / 8)) * 8;
             if (row < o.valid && c8 < kvalid) {
                 vh = *reinterpret_cast<const uint4*>(o.hi + (size_t)row * o.ld + k0 + c8);
                 vl = *reinterpret_cast<const uint4*>(o.lo + (size_t)row * o.ld + k0 + c8);
             }
-        } else {    // tile [64 K-rows][128 cols]
-            const int row = idx >> 4, c8 = (idx & 15) * 8;
+        } else {    // tile [KS K-rows][T cols]
+            const int row = idx / (T / 8), c8 = (idx % (T / 8)) * 8;
             if (row < kvalid && c8 < o.valid) {
                 vh = *reinterpret_cast<const uint4*>(o.hi + (size_t)(k0 + row) * o.ld + c8);
                 vl = *reinterpret_cast<const uint4*>(o.lo + (size_t)(k0 + row) * o.ld + c8);
@@ -101,59 +116,72 @@ __device__ __forceinline__ void gemm_fetch(const Opnd& o, int k0, int kvalid, in
         rh[i] = vh; rl[i] = vl;
     }
 }
-template <bool KC>
-__device__ __forceinline__ void gemm_stash(_Float16* th, _Float16* tl, int tid, const uint4 (&rh)[4], const uint4 (&rl)[4]) {
+template <class C, bool KC, int T>
+__device__ __forceinline__ void gemm_stash(_Float16* th, _Float16* tl, int tid, const uint4 (&rh)[C::NP], const uint4 (&rl)[C::NP]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        const int off = KC ? (idx >> 3) * KP + (idx & 7) * 8 : (idx >> 4) * RP + (idx & 15) * 8;
+    for (int i = 0; i < C::NP; ++i) {
+        const int idx = tid + C::NT * i;
+        const int off = KC ? (idx / (C::KS / 8)) * C::KP + (idx % (C::KS / 8)) * 8
+                           : (idx / (T / 8)) * (T + 16) + (idx % (T / 8)) * 8;
         *reinterpret_cast<uint4*>(th + off) = rh[i];
         *reinterpret_cast<uint4*>(tl + off) = rl[i];
     }
 }
-template <bool KC>
+template <class C, bool KC, int T>
 __device__ __forceinline__ h8 gemm_frag(const _Float16* t, int blk0, int s, int lane) {
-    if (KC) return frag_row(t + (blk0 + (lane & 31)) * KP + 8 * (lane >> 5) + 16 * s);
-    return frag_tr(t, RP, 16 * s, blk0, lane);
+    if (KC) return frag_row(t + (blk0 + (lane & 31)) * C::KP + 8 * (lane >> 5) + 16 * s);
+    return frag_tr(t, T + 16, 16 * s, blk0, lane);
 }
 
-// acc[a2][b2] += A[64 wa + 32 a2 ..][K] . B[64 wb + 32 b2 ..][K]  over K = [0, ktotal)
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void gemm128(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
-                                        f32x16 (&acc)[2][2]) {
+// acc[a2][b2] += A[wave rows + 32 a2 ..][K] . B[wave cols + 32 b2 ..][K]  over K = [0, ktotal)
+template <class C, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
+                                          f32x16 (&acc)[C::A2][C::B2]) {
+    constexpr int KS = C::KS;
     _Float16* const Ah = sm;
-    _Float16* const Al = sm + PLANE;
-    _Float16* const Bh = sm + 2 * PLANE;
-    _Float16* const Bl = sm + 3 * PLANE;
-    const int lane = tid & 63, wid = tid >> 6, wa = wid >> 1, wb = wid & 1;
-    uint4 pah[4], pal[4], pbh[4], pbl[4];
-    gemm_fetch<AKC>(A, 0, min(64, ktotal), tid, pah, pal);
-    gemm_fetch<BKC>(B, 0, min(64, ktotal), tid, pbh, pbl);
-    for (int k0 = 0; k0 < ktotal; k0 += 64) {
-        gemm_stash<AKC>(Ah, Al, tid, pah, pal);
-        gemm_stash<BKC>(Bh, Bl, tid, pbh, pbl);
+    _Float16* const Al = sm + C::PLANE_A;
+    _Float16* const Bh = sm + 2 * C::PLANE_A;
+    _Float16* const Bl = Bh + C::PLANE_B;
+    const int lane = tid & 63, wid = tid >> 6, wa = wid / C::WN, wb = wid % C::WN;
+    const int arow0 = wa * (32 * C::A2), bcol0 = wb * (32 * C::B2);
+    uint4 pah[C::NP], pal[C::NP], pbh[C::NP], pbl[C::NP];
+    gemm_fetch<C, AKC, C::TM>(A, 0, min(KS, ktotal), tid, pah, pal);
+    gemm_fetch<C, BKC, C::TN>(B, 0, min(KS, ktotal), tid, pbh, pbl);
+    for (int k0 = 0; k0 < ktotal; k0 += KS) {
+        gemm_stash<C, AKC, C::TM>(Ah, Al, tid, pah, pal);
+        gemm_stash<C, BKC, C::TN>(Bh, Bl, tid, pbh, pbl);
         __syncthreads();
-        if (k0 + 64 < ktotal) {   // next K-step's operands: in flight under the MFMAs below
-            gemm_fetch<AKC>(A, k0 + 64, min(64, ktotal - k0 - 64), tid, pah, pal);
-            gemm_fetch<BKC>(B, k0 + 64, min(64, ktotal - k0 - 64), tid, pbh, pbl);
+        if (k0 + KS < ktotal) {   // next K-step's operands: in flight under the MFMAs below
+            gemm_fetch<C, AKC, C::TM>(A, k0 + KS, min(KS, ktotal - k0 - KS), tid, pah, pal);
+            gemm_fetch<C, BKC, C::TN>(B, k0 + KS, min(KS, ktotal - k0 - KS), tid, pbh, pbl);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            h8 ah[2], al[2], bh[2], bl[2];
+        for (int s = 0; s < KS / 16; ++s) {
+            h8 bh[C::B2], bl[C::B2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                ah[u] = gemm_frag<AKC>(Ah, 64 * wa + 32 * u, s, lane);
-                al[u] = gemm_frag<AKC>(Al, 64 * wa + 32 * u, s, lane);
-                bh[u] = gemm_frag<BKC>(Bh, 64 * wb + 32 * u, s, lane);
-                bl[u] = gemm_frag<BKC>(Bl, 64 * wb + 32 * u, s, lane);
+            for (int u = 0; u < C::B2; ++u) {
+                bh[u] = gemm_frag<C, BKC, C::TN>(Bh, bcol0 + 32 * u, s, lane);
+                bl[u] = gemm_frag<C, BKC, C::TN>(Bl, bcol0 + 32 * u, s, lane);
             }
 #pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2)
+            for (int a2 = 0; a2 < C::A2; ++a2) {
+                const h8 ah = gemm_frag<C, AKC, C::TM>(Ah, arow0 + 32 * a2, s, lane);
+                const h8 al = gemm_frag<C, AKC, C::TM>(Al, arow0 + 32 * a2, s, lane);
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) acc[a2][b2] = mfma3(ah[a2], al[a2], bh[b2], bl[b2], acc[a2][b2]);
+                for (int b2 = 0; b2 < C::B2; ++b2) acc[a2][b2] = mfma3(ah, al, bh[b2], bl[b2], acc[a2][b2]);
+            }
         }
         __syncthreads();
     }
+}
+template <class C>
+__device__ __forceinline__ void gemm_zero(f32x16 (&acc)[C::A2][C::B2]) {
+#pragma unroll
+    for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
 }
 
 }  // namespace
@@ -244,44 +272,40 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per 128 x 128 tile (gemm128, both operands K-contiguous).
-__global__ __launch_bounds__(256, 2) void ge2e_tiled_sim(Problem p, TiledWs L) {
+// k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per TM x TN tile (both operands K-contiguous).
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L) {
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M;
-    const int rt = (NM + 127) / 128, ct = (N + 127) / 128;
+    const int rt = (NM + C::TM - 1) / C::TM, ct = (N + C::TN - 1) / C::TN;
     int t = blockIdx.x;
     const int kt = t % ct; t /= ct;
     const int rtile = t % rt;
     const int bi = t / rt;
     const size_t NMp = (size_t)NM;
     Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * 128 * D;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * C::TM * D;
     A.lo = A.hi + NMp * D;
-    A.ld = D; A.valid = min(128, NM - rtile * 128);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * 128 * D;
+    A.ld = D; A.valid = min(C::TM, NM - rtile * C::TM);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * C::TN * D;
     Bo.lo = Bo.hi + (size_t)N * D;
-    Bo.ld = D; Bo.valid = min(128, N - kt * 128);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
-    gemm128<true, true>(A, Bo, D, gsm, tid, acc);
+    Bo.ld = D; Bo.valid = min(C::TN, N - kt * C::TN);
+    f32x16 acc[C::A2][C::B2];
+    gemm_zero<C>(acc);
+    gemm_tile<C, true, true>(A, Bo, D, gsm, tid, acc);
     float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
+    for (int a2 = 0; a2 < C::A2; ++a2)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int r = rtile * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
+            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
+            for (int b2 = 0; b2 < C::B2; ++b2) {
                 float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
                 quad_transpose4(x, lane);
-                const int k = kt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                const int k = kt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
                 if (r < NM && k < L.npad)
                     *reinterpret_cast<float4*>(X + (size_t)r * L.npad + k) =
                         make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
@@ -524,44 +548,40 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (128 centroids x 128 d) tile over all rows of the
-// batch (gemm128, both operands with K along their rows -> transposing reads).
-__global__ __launch_bounds__(256, 2) void ge2e_tiled_gc(Problem p, TiledWs L) {
+// k_gc: gC[k][d] = sum_r GH[r][k] EH[r][d].  One workgroup per (TM centroids x TN d) tile over all rows of the batch
+// (both operands with K along their rows -> transposing reads).
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) {
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M, npad = L.npad;
-    const int dtiles = (D + 127) / 128, ct = (N + 127) / 128;
+    const int dtiles = (D + C::TN - 1) / C::TN, ct = (N + C::TM - 1) / C::TM;
     int t = blockIdx.x;
     const int dt = t % dtiles; t /= dtiles;
     const int kt = t % ct;
     const int bi = t / ct;
     Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * 128;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * C::TM;
     A.lo = A.hi + (size_t)NM * npad;
-    A.ld = npad; A.valid = min(128, npad - kt * 128);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * 128;
+    A.ld = npad; A.valid = min(C::TM, npad - kt * C::TM);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * C::TN;
     Bo.lo = Bo.hi + (size_t)NM * D;
-    Bo.ld = D; Bo.valid = min(128, D - dt * 128);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
-    gemm128<false, false>(A, Bo, NM, gsm, tid, acc);
+    Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
+    f32x16 acc[C::A2][C::B2];
+    gemm_zero<C>(acc);
+    gemm_tile<C, false, false>(A, Bo, NM, gsm, tid, acc);
     float* GC = p.ws + L.gc + (size_t)bi * N * D;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
+    for (int a2 = 0; a2 < C::A2; ++a2)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int k = kt * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
+            const int k = kt * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
+            for (int b2 = 0; b2 < C::B2; ++b2) {
                 float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
                 quad_transpose4(x, lane);
-                const int d = dt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
                 if (k < N && d < D)
                     *reinterpret_cast<float4*>(GC + (size_t)k * D + d) =
                         make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
@@ -622,32 +642,28 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (128 rows x 128 d) tile (gemm128: A K-contiguous, B K-rows), then the
-// epilogue dE = ra gE + c1e e + rc c-hat_j + KJ_j.
-__global__ __launch_bounds__(256, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
+// k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (TM rows x TN d) tile (A K-contiguous, B K-rows), then the epilogue
+// dE = ra gE + c1e e + rc c-hat_j + KJ_j.
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
-    const int dtiles = (D + 127) / 128, rt = (NM + 127) / 128;
+    const int dtiles = (D + C::TN - 1) / C::TN, rt = (NM + C::TM - 1) / C::TM;
     int t = blockIdx.x;
     const int dt = t % dtiles; t /= dtiles;
     const int rtile = t % rt;
     const int bi = t / rt;
     Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * 128 * npad;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * C::TM * npad;
     A.lo = A.hi + (size_t)NM * npad;
-    A.ld = npad; A.valid = min(128, NM - rtile * 128);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * 128;
+    A.ld = npad; A.valid = min(C::TM, NM - rtile * C::TM);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * C::TN;
     Bo.lo = Bo.hi + (size_t)N * D;
-    Bo.ld = D; Bo.valid = min(128, D - dt * 128);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
-    gemm128<true, false>(A, Bo, N, gsm, tid, acc);   // K = the N real centroid slots (pad columns of GH are zero)
+    Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
+    f32x16 acc[C::A2][C::B2];
+    gemm_zero<C>(acc);
+    gemm_tile<C, true, false>(A, Bo, N, gsm, tid, acc);   // K = the N real centroid slots (pad columns of GH are zero)
     const float* E = p.E + (size_t)bi * NM * D;
     float* dE = p.dE + (size_t)bi * NM * D;
     const float* CHf = p.ws + L.chf + (size_t)bi * N * D;
@@ -655,21 +671,21 @@ __global__ __launch_bounds__(256, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
     const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
     // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
     // columns: every global access of the epilogue is 16 bytes wide (8 rows x 128 B per wave-instruction)
-    const int l31 = lane & 31, h = lane >> 5, wa = wid >> 1, wb = wid & 1, pq = lane & 3, cq = l31 >> 2;
+    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
+    for (int a2 = 0; a2 < C::A2; ++a2)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int r = rtile * 128 + 64 * wa + 32 * a2 + 8 * g + 4 * h + pq;
+            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
             const bool rv = r < NM;
             const int rc = rv ? r : NM - 1;
             const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)rc * 8);  // ra c1e c2s c3
             const int j = rc / M;
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
+            for (int b2 = 0; b2 < C::B2; ++b2) {
                 float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
                 quad_transpose4(x, lane);
-                const int d = dt * 128 + 64 * wb + 32 * b2 + 4 * cq;
+                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
                 if (rv && d < D) {
                     const float4 e = *reinterpret_cast<const float4*>(E + (size_t)r * D + d);
                     const float4 c = *reinterpret_cast<const float4*>(CHf + (size_t)j * D + d);
@@ -737,26 +753,50 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const int NM = p.N * p.M;
     const unsigned spk_blocks = (unsigned)((p.B * p.N + 3) / 4);
     const unsigned row_blocks = (unsigned)(((size_t)p.B * NM + 3) / 4);
+    typedef GemmCfg<128, 128> C1;
+    typedef GemmCfg<256, 256> C2;
     static bool attr_done = false;
     if (!attr_done) {
-        for (const void* fn : {reinterpret_cast<const void*>(ge2e_tiled_sim), reinterpret_cast<const void*>(ge2e_tiled_gc),
-                               reinterpret_cast<const void*>(ge2e_tiled_ge)}) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+        const void* small[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), reinterpret_cast<const void*>(ge2e_tiled_gc<C1>),
+                               reinterpret_cast<const void*>(ge2e_tiled_ge<C1>)};
+        const void* big[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), reinterpret_cast<const void*>(ge2e_tiled_gc<C2>),
+                             reinterpret_cast<const void*>(ge2e_tiled_ge<C2>)};
+        for (const void* fn : small) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        for (const void* fn : big) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2::LDS_BYTES);
             if (e != hipSuccess) return e;
         }
         attr_done = true;
     }
-    const unsigned rt128 = (unsigned)((NM + 127) / 128), ct128 = (unsigned)((p.N + 127) / 128), dt128 = (unsigned)((p.D + 127) / 128);
+    auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
+    // the 256 x 256 tile where both extents of the contraction's output reach it AND its grid still gives every CU
+    // most of the CUs a workgroup (a single batch of cfg5 has 160 big tiles), else 128 x 128
+    const unsigned fill = 192;   // (measured: the long-K gC contraction gains from the big tile even at one workgroup per CU)
+    const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= fill;
+    const bool big_gc = p.N >= 256 && p.D >= 256 && (unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) >= fill;
+    const bool big_ge = NM >= 256 && p.D >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256) >= fill;
     hipLaunchKernelGGL(ge2e_tiled_prep, dim3(spk_blocks), dim3(256), 0, stream, p, L);
-    hipLaunchKernelGGL(ge2e_tiled_sim, dim3((unsigned)p.B * rt128 * ct128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
+    if (big_sim)
+        hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    else
+        hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
     if (L.npad <= 256)
         hipLaunchKernelGGL(ge2e_tiled_rows16, dim3((unsigned)(((size_t)p.B * NM + 15) / 16)), dim3(256), 0, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
     if (p.dE) {
-        hipLaunchKernelGGL(ge2e_tiled_gc, dim3((unsigned)p.B * ct128 * dt128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
+        if (big_gc)
+            hipLaunchKernelGGL(ge2e_tiled_gc<C2>, dim3((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        else
+            hipLaunchKernelGGL(ge2e_tiled_gc<C1>, dim3((unsigned)p.B * tiles(p.N, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
         hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
-        hipLaunchKernelGGL(ge2e_tiled_ge, dim3((unsigned)p.B * rt128 * dt128), dim3(256), GEMM_LDS_BYTES, stream, p, L);
+        if (big_ge)
+            hipLaunchKernelGGL(ge2e_tiled_ge<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        else
+            hipLaunchKernelGGL(ge2e_tiled_ge<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
     }
     hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
     return hipGetLastError();
