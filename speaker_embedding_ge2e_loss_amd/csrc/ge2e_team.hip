@@ -188,9 +188,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, q = lane >> 4;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int pq = lane & 3, cq15 = l15 >> 2, cq31 = l31 >> 2;
     const int d4 = 4 * lane;
     const bool dact = d4 < D;
     const int kh = wid >> 2, sl = wid & 3;
@@ -254,10 +251,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
             rowv[i] = bload4(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
     } while (0)
-    const int ir = 4 * q + pq;                                  // the row this lane holds in the tile layout
-    const bool irv = ir < M;
-    const int irc = min(ir, M - 1);
-    const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;
 
     // Lane-derived indices are re-derived inside each phase from an opaque copy of the lane id.  As loop
     // invariants they were hoisted out of the batch loop, spilled under the register peaks, and reloaded from
