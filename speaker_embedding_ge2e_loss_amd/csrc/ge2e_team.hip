@@ -7,21 +7,25 @@
 // become phases over resident data with two exchanges through the XCD's L2 in between
 // (ge2e_team.hpp: team formation and the hand-off protocol):
 //
-//   P1  wave s owns local speaker s: load its M rows, |e|, e-hat -> ET images; speaker sum -> unit
-//       centroid (scaled 2^8) -> published to the team                                   [hand-off 1]
-//   P2  all 64 published centroids -> CH images (every member, identical bits)
+//   P1  wave s owns local speaker s: its M rows (requested a phase-group earlier) -> speaker sum -> unit
+//       centroid, published to the team as finished fp16 hi / lo image rows             [hand-off 1];
+//       per row |e|, e-hat -> ET images
+//   P2  all 64 published centroid rows -> CH images (a pure copy, identical bits on every member)
 //   P3  X[k][r] = CH . ET^T for the wave's own 16 (>= M) rows: 16 x 16 x 32 split-fp16 MFMA tiles;
-//       lane (r = lane & 15, q = lane >> 4) ends up with X[16 t + 4 q + i][r]
+//       lane (r = lane & 15, q = lane >> 4) ends up with X[16 t + 4 q + i][r].  Each K-step also stores
+//       two finished 16-byte tiles of the PREVIOUS batch's dE (the only write of dE)
 //   P4  leave-one-out statistics, softmax / contrast, dL/dS -- in registers: a row's 64 columns sit
 //       in 16 registers of 4 lanes (l, l^16, l^32, l^48)
-//   P5  gE = G . CH with G taken straight from those registers as the A operand (no LDS trip), the
-//       KJ-independent part of dE (ra gE + c1 e-hat + rc c-hat_j) stays in registers (64 VGPRs);
-//       per-speaker row KJP_j = sum_i c3_i e-hat_i + (sum_i c4_i) s_j  (all rows of j are in this wave)
-//   P6  G -> fp16 hi / lo images over the (now dead) centroid images
+//   P5  per-speaker row KJP_j = sum_i c3_i e-hat_i + (sum_i c4_i) s_j (all rows of j are in this wave;
+//       c3_i broadcast by v_readlane); gE = G . CH with G taken straight from the registers as the A
+//       operand (no LDS trip), three tiles in flight; ra gE + c1 e-hat stays in registers (64 VGPRs)
+//   P6  G (the same fp16 fragments) -> hi / lo images over the (now dead) centroid images
 //   P7  partial gC[k][d] = sum_{own rows} G[r][k] e-hat[r][d] (32 x 32 x 16 tiles, all 8 waves)
 //       -> published, with the member's loss / dw / db partials                          [hand-off 2]
 //   P8  wave s sums the eight partials of ITS speaker in member order, maps them through the
-//       centroid norm -> KJ_j, adds it to the held rows and stores dE (once).
+//       centroid norm -> KJ_j; held rows += rc c-hat_j + KJ_j: dE complete, stored under the next P3.
+// The loop is rotated (P1 of batch n runs before P8 of batch n - 1, one drain + barrier signals both
+// hand-offs; see the comment at the loop) so that no wait is exposed.
 //
 // HBM traffic per batch: E read once, dE written once (+ the published rows: 64 KB centroids and
 // 8 x 64 KB partial gradients, which live in L2 and are written through once).
