@@ -76,3 +76,29 @@ def test_auto_uses_team_for_few_batches(GF):
     assert GF.resolve_impl(1, 4, 5, 256, "softmax", "auto") == "fused_split"     # too few speakers for eight members
     with pytest.raises(RuntimeError):
         GF.resolve_impl(1, 64, 20, 256, "softmax", "team")                        # M > 16
+
+
+def test_hand_off_protocol_stress(GF):
+    """400 launches of a multi-batch-per-team problem: every launch bitwise equal to the first
+    (a stale or torn read in the L2 hand-offs would show as a different bit pattern somewhere)."""
+    B, N, M, D = 72, 64, 10, 256
+    E = orc.synth_embeddings((B, N, M, D), "unit", seed=99)
+    dev = torch.device("cuda:0")
+    e = torch.as_tensor(E, device=dev)
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", "team"), dev)
+    first = None
+    for it in range(400):
+        out = GF.LossOutputs(loss=torch.full((B,), float("nan"), device=dev), per=None,
+                             dE=torch.full((B, N, M, D), float("nan"), device=dev),
+                             dw=torch.full((B,), float("nan"), device=dev), db=torch.full((B,), float("nan"), device=dev))
+        GF.loss_fwd_bwd(e, w, b, impl="team", out=out, workspace=ws)
+        if first is None:
+            torch.cuda.synchronize()
+            first = (out.loss.clone(), out.dE.clone(), out.dw.clone(), out.db.clone())
+            ref = orc.closed_form(E[7], 10.0, -5.0)
+            assert rel_fro(first[1][7].cpu().numpy(), ref["dE"]) < 2e-5
+        elif it % 25 == 0 or it == 399:
+            torch.cuda.synchronize()
+            assert torch.equal(out.loss, first[0]) and torch.equal(out.dE, first[1]), it
+            assert torch.equal(out.dw, first[2]) and torch.equal(out.db, first[3]), it
