@@ -254,7 +254,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         // tile rows in registers: v[g][c] = row 8 wid + 4 g + sub, columns 64 c + 4 l16 .. +3;
         // rows past the tile's last speaker get the out-of-range lane offset and read 0.
         float4 v[2][NCH];
-#define GE2E_LOAD_ROWS(T) GE2E_LOAD_ROWS_AUX(T, 0)
+#ifndef GE2E_AUX_E2
+#define GE2E_AUX_E2 0   // sweep-2 read of E
+#endif
+#define GE2E_LOAD_ROWS(T) GE2E_LOAD_ROWS_AUX(T, GE2E_AUX_E2)
 #define GE2E_LOAD_ROWS_AUX(T, AUX)                                                          \
     do {                                                                                    \
         const int j0_ = (T) * spt;                                                          \
