@@ -664,7 +664,10 @@ FusedWs fused_split_layout(int N, int M, int D) {
     return L;
 }
 
-int fused_split_grid(int B) { return B < 256 ? B : 256; }
+#ifndef GE2E_SPLIT_GRID
+#define GE2E_SPLIT_GRID 256   // one workgroup per CU (tools/exp_cache_policy.py --grid: fewer did not pay)
+#endif
+int fused_split_grid(int B) { return B < GE2E_SPLIT_GRID ? B : GE2E_SPLIT_GRID; }
 
 size_t fused_split_workspace_bytes(int B, int N, int M, int D) {
     return (size_t)fused_split_grid(B) * fused_split_layout(N, M, D).stride * sizeof(float);
