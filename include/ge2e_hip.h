@@ -48,6 +48,9 @@ extern "C" {
                                    v_mfma_f32_32x32x16_f16, fp32 accumulate      */
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
 #define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, E resident in LDS: E read once */
+#define GE2E_IMPL_TEAM2 6       /* as TEAM on flat 16-row blocks, centroid operands in registers, one
+                                   exchange buffer per team; falls back to FUSED_SPLIT inside the same
+                                   call if the teams cannot form                                        */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */

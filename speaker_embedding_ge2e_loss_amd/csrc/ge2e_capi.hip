@@ -10,6 +10,7 @@
 #include "ge2e_selftest.hpp"
 #include "ge2e_tiled.hpp"
 #include "ge2e_team.hpp"
+#include "ge2e_team2.hpp"
 
 using namespace ge2e;
 
@@ -38,6 +39,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_ERR_IMPL;
         case GE2E_IMPL_TILED: return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_ERR_IMPL;
         case GE2E_IMPL_TEAM: return team_supports(N, M, D) ? GE2E_IMPL_TEAM : GE2E_ERR_IMPL;
+        case GE2E_IMPL_TEAM2: return team2_supports(N, M, D) ? GE2E_IMPL_TEAM2 : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -49,6 +51,7 @@ size_t ws_bytes(int B, int N, int M, int D, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TILED: return tiled_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TEAM: return team_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_TEAM2: return team2_workspace_bytes(B, N, M, D);
         default: return 0;
     }
 }
@@ -73,6 +76,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
         case GE2E_IMPL_FUSED_SPLIT: err = launch_fused_split(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TILED: err = launch_tiled(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TEAM: err = launch_team(p, (hipStream_t)stream); break;
+        case GE2E_IMPL_TEAM2: err = launch_team2(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;

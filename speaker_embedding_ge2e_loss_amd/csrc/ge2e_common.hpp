@@ -27,6 +27,8 @@ struct Problem {
     float eps;        // hp.general.small_err (1e-6)
     float log_eps;    // logf(eps), -inf when eps == 0
     unsigned long long* prof;  // diagnostic builds (-DGE2E_PROFILE) only: per-phase cycle sums
+    const unsigned* gate;      // non-null: the launch is a fall-back that runs only if *gate != 0 (ge2e_team2.hip)
+    int grid_cap;              // > 0: at most this many workgroups (the fall-back's workspace is sized for it)
 };
 
 // In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with

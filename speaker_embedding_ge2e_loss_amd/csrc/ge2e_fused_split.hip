@@ -150,6 +150,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const int sl = wid & 3;           //                        64-column slice of d
     const bool slice_on = 64 * sl < D;
 
+    // fall-back launch behind the team kernel (ge2e_team2.hip): nothing to do unless its abort word is up
+    if (p.gate && __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int spt = wsl.spt;          // speakers per tile
     const int ntiles = wsl.ntiles;
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
@@ -678,7 +680,9 @@ static hipError_t launch_nch(const Problem& p, const FusedWs& L, size_t lds, hip
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_fused_split_kernel<NCH>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(ge2e_fused_split_kernel<NCH>, dim3(fused_split_grid(p.B)), dim3(512), lds, stream, p, L);
+    int grid = fused_split_grid(p.B);
+    if (p.grid_cap > 0 && grid > p.grid_cap) grid = p.grid_cap;
+    hipLaunchKernelGGL(ge2e_fused_split_kernel<NCH>, dim3(grid), dim3(512), lds, stream, p, L);
     return hipGetLastError();
 }
 

@@ -48,6 +48,9 @@ constexpr int MAXM = 16;     // rows of one speaker = one 16-row MFMA block
 constexpr unsigned OOB = 0x7FFFFF00u;
 constexpr int AUX_L2 = 16;   // sc1: served by L2, never by this CU's L1 (hand-off reads)
 constexpr int AUX_NT = 2;
+#ifndef GE2E_TEAM_E_AUX
+#define GE2E_TEAM_E_AUX 0
+#endif
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         const bool on_ = has_spk && (BI) < p.B;                                                          \
         const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
-            rowv[i] = bload4(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+            rowv[i] = bload4<GE2E_TEAM_E_AUX>(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
     } while (0)
 
     // Lane-derived indices are re-derived inside each phase from an opaque copy of the lane id.  As loop

@@ -1,0 +1,806 @@
+// GE2E_IMPL_TEAM2: eight workgroups on eight CUs of one XCD share a batch; E is read from HBM ONCE and every
+// phase works on flat 16-row blocks of the member's rows, so nothing is padded from M rows to an MFMA block.
+//
+// Member m of a team owns the speaker slots 8 m .. 8 m + spm - 1 (spm = ceil(N / 8)) and their R = spm M rows.
+// LDS holds only the member's OWN data: its rows as fp16 hi / lo unit-row images ET (87 KB at N=64, M=10, D=256),
+// the similarity block X (two K-halves, fp32) and the dL/dS images G.  The 64 unit centroids never enter LDS: each
+// wave keeps the MFMA fragments it needs in registers, loaded straight from the team's L2-resident exchange area
+// (row-major for X = ET . CH^T, and as 16-byte k-groups per column for gE = G . CH).
+//
+//   A    wave s = speaker slot s: its M rows (prefetched registers) -> |e|, e-hat -> ET images; speaker sum ->
+//        unit centroid -> published in both forms                                                   [hand-off 1]
+//   B    centroid fragments -> registers (64 VGPRs); beside it FINISH of the previous batch: the eight partial
+//        centroid gradients of my speaker -> KJ_j -> dE = held + KJ_j -> HBM (the only write of dE)
+//   X    wave (t, kh): X[all rows][slots 16 t ..] over the K half kh -> LDS (60 MFMAs a wave, SIMD-balanced)
+//   S    softmax / contrast on X, 16 lanes per row: leave-one-out statistics, loss, dL/dS -> G images,
+//        row coefficients
+//   GC   partial gC^T[d][k] = sum_r ET[r][d] G[r][k] (32 x 32 x 16 tiles) -> published                [hand-off 2]
+//   GE   gE[d][r] = sum_k CH[k][d] G[r][k] with the centroid fragments from registers; ra gE + c1 e-hat is held
+//        in registers (40 VGPRs) until the partial gradients of the other members arrive
+// The own-speaker column of a row carries the coefficient of s_j in the G image (so GE adds that term for free);
+// what that entry adds to the member's own partial gC is taken out again algebraically in KJ_j (see S).
+//
+// Exchange per batch and team: 128 KB of centroids (double-buffered) + 512 KB of partial gradients in ONE buffer,
+// guarded by a read-done counter, so the four teams of an XCD keep 2.6 MB live in its 4 MiB L2.
+#include "ge2e_common.hpp"
+#include "ge2e_split_gemm.hpp"
+#include "ge2e_team.hpp"
+#include "ge2e_team2.hpp"
+#include "ge2e_fused.hpp"
+
+namespace ge2e {
+
+#ifdef GE2E_T2_DEBUG
+__device__ unsigned* g_t2_dbg = nullptr;   // [B][8 members][16 items][512 threads]
+__device__ unsigned* g_t2_dump = nullptr;  // [B][8 members][32768] dwords
+#define T2_DBG(batch, item, val)                                                                              \
+    do {                                                                                                      \
+        if (g_t2_dbg) g_t2_dbg[(((size_t)(batch) * 8 + id.member) * 16 + (item)) * 512 + threadIdx.x] = (val); \
+    } while (0)
+__device__ __forceinline__ unsigned t2_x4(const float4& v) {
+    return __float_as_uint(v.x) ^ (__float_as_uint(v.y) * 3u) ^ (__float_as_uint(v.z) * 5u) ^ (__float_as_uint(v.w) * 7u);
+}
+#else
+#define T2_DBG(batch, item, val)
+#endif
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NC = 64;        // centroid slots: member m owns 8 m .. 8 m + 7
+constexpr int GP = 72;        // G image pitch (halfs)
+constexpr int XP = 68;        // X block pitch (floats)
+constexpr int RTMAX = 80;     // rows of a member's images
+constexpr int RBMAX = RTMAX / 16;
+constexpr unsigned OOB = 0x7FFFFF00u;
+constexpr int AUX_L2 = 16;    // sc1: served by L2, never by this CU's L1 (hand-off reads)
+constexpr int AUX_NT = 2;
+#ifndef GE2E_T2_ST_AUX
+#define GE2E_T2_ST_AUX 0      // cache policy of the exchange stores (experiments: 16 = sc1, write-through)
+#endif
+#ifndef GE2E_T2_RELEASE
+#define GE2E_T2_RELEASE 0     // experiments: agent-scope release fence before the hand-off signals
+#endif
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 scale4(const float4& a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int AUX = 0>
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ h8 bload_h8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+// whole offset in the VGPR, immediate soffset (ge2e_fused_split.hip: the register-soffset store hazard)
+template <int AUX = 0>
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, const float4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, AUX);
+}
+__device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
+    if (sq > eps_cos * eps_cos && sq < 1e30f) {
+        float r = __builtin_amdgcn_rsqf(sq);
+        r = r * (1.5f - 0.5f * sq * r * r);
+        rn = r;
+        kappa = 1.0f;
+    } else {
+        unit_stats(sq, eps_cos, rn, kappa);
+    }
+}
+__device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
+    h4 hi, lo;
+    split4(x, hi, lo);
+    *reinterpret_cast<h4*>(hi_img + off) = hi;
+    *reinterpret_cast<h4*>(lo_img + off) = lo;
+}
+
+// MFMAs as inline asm with the accumulator TIED to the destination.  With the builtins hipcc is free to give a chain
+//   v[12:15] = A.B + 0 ;  v[8:11] = A.B' + v[12:15] ;  ds_read_b128 v[12:15], ...   (next fragment into the dead SrcC)
+// and on gfx950 the matrix pipe reads SrcC pass by pass: when the pipe is shared with the SIMD's other wave the MFMA
+// can start late, the LDS read lands first, and the rows of the LAST pass (accumulator lanes 48..63) pick up the new
+// fragment bits instead of the partial sum.  Found with per-thread checksums of two identical launches: every input of
+// GE identical, `held` different in lanes q = 3 only, in 5-75 % of the launches depending on how long the phase ran.
+// A tied accumulator is only ever written by the (in-order) matrix pipe.  hipcc pads nothing around asm, so the wait
+// states between the last MFMA of a chain and the first read of its result are spelled out (T2_SETTLE*).
+__device__ __forceinline__ void mfma16(f32x4& acc, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32(f32x16& acc, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// acc += (ah + al) . (bh + bl) without the lo.lo term
+__device__ __forceinline__ void mfma16x3(f32x4& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
+    mfma16(acc, ah, bh); mfma16(acc, ah, bl); mfma16(acc, al, bh);
+}
+__device__ __forceinline__ void mfma32x3(f32x16& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
+    mfma32(acc, ah, bh); mfma32(acc, ah, bl); mfma32(acc, al, bh);
+}
+#define T2_SETTLE16(acc) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc))                  /* 16x16x32: 8 passes  */
+#define T2_SETTLE32(a0, a1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))  /* 32x32x16: 16 passes */
+__device__ __forceinline__ f32x4 acc_zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(z));    // a register, not the inline constant 0: the chain starts in its final home
+    return z;
+}
+
+// one lane waits; the result travels through an LDS word that is not reused for four waits (there is a
+// workgroup barrier between any two of them), so ONE barrier per wait is enough
+__device__ __forceinline__ bool team2_wait(const unsigned* counter, unsigned target, TeamCtl* ctl, int* sh, int& slot) {
+    int* w = sh + (slot & 3);
+    ++slot;
+    if (threadIdx.x == 0) *w = spin_until(counter, target, ctl) ? 1 : 0;
+    __syncthreads();
+    return *w != 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+static int team2_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 0;
+}
+
+Team2Ws team2_layout(int N, int M, int D) {
+    Team2Ws L{};
+    L.spm = (N + TEAM - 1) / TEAM;
+    L.rt = (L.spm * M + 15) / 16 * 16;
+    L.mul_m = (65536 + M - 1) / M;
+    unsigned o = 0;
+    for (int b = 0; b < 2; ++b) { L.chr[b] = o; o += (unsigned)NC * 2 * D * 2; }
+    for (int b = 0; b < 2; ++b) { L.cht[b] = o; o += (unsigned)TEAM * 2 * D * 16; }
+    for (int b = 0; b < 2; ++b) { L.cst[b] = o; o += NC * 16; }
+    for (int b = 0; b < 2; ++b) { L.sc[b] = o; o += TEAM * 16; }
+    o = (unsigned)align_up(o, 256);
+    L.gc = o; o += (unsigned)TEAM * NC * D * 4;
+    L.stride = align_up(o, 4096);
+    L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(Team2Flags), 256);
+    const int P = D + 16;
+    const size_t et = (size_t)2 * L.rt * P * 2;
+    size_t xb = (size_t)L.rt * XP * 4;                 // X half-block; the second one also stages the transposed centroid
+    if (xb < (size_t)D * 32) xb = (size_t)D * 32;
+    size_t g = (size_t)2 * L.rt * GP * 2;              // G images; also the KJ rows [8][D] of the finish phase
+    if (g < (size_t)8 * D * 4) g = (size_t)8 * D * 4;
+    L.xb_bytes = (unsigned)xb;
+    L.g_bytes = (unsigned)g;
+    L.lds_bytes = et + 2 * xb + g + (size_t)(L.rt * 8 + NC * 4 + 32 + 16) * sizeof(float);
+    return L;
+}
+
+bool team2_supports(int N, int M, int D) {
+    if (!(N >= 1 && N <= NC && M >= 2 && M <= 16 && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
+    const Team2Ws L = team2_layout(N, M, D);
+    if (L.rt > RTMAX || L.lds_bytes > 160 * 1024) return false;
+    if (!fused_split_supports(N, M, D)) return false;            // the gated fall-back launch
+    return team2_cu_count() >= MAX_XCD * TEAM;                    // partitioned device: no XCD-wide teams to form
+}
+
+// workgroups: one per CU, but no more than eight XCDs' worth of teams for the batches there are
+int team2_grid(int B) {
+    const int cus = team2_cu_count() / (MAX_XCD * TEAM) * (MAX_XCD * TEAM);
+    const long want = (long)((B + MAX_XCD - 1) / MAX_XCD) * (MAX_XCD * TEAM);
+    return (int)(want < cus ? want : cus);
+}
+static size_t team2_fb_bytes(int B, int N, int M, int D) {
+    const int g = B < TEAM2_FALLBACK_GRID ? B : TEAM2_FALLBACK_GRID;
+    return (size_t)g * fused_split_layout(N, M, D).stride * sizeof(float);
+}
+size_t team2_workspace_bytes(int B, int N, int M, int D) {
+    const Team2Ws L = team2_layout(N, M, D);
+    return align_up(L.head_bytes + (size_t)(team2_grid(B) / TEAM) * L.stride, 256) + team2_fb_bytes(B, N, M, D);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NCH, int MR>  // D = 64 * NCH; MR >= M rows of a speaker are prefetched into registers
+__global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int D = 64 * NCH;
+    constexpr int P = D + 16;             // image pitch: rows 8 banks apart (b128 row reads AND transposing reads)
+    constexpr unsigned ROWB = D * 4;
+    constexpr int NT = 4 * NCH;           // 16-column tiles of a row
+    constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
+    const int RT = L.rt, RB = RT / 16;
+    _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
+    _Float16* const ETl = ETh + RT * P;
+    float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
+    float* const XB1 = XB0 + L.xb_bytes / 4;
+    _Float16* const Gh = reinterpret_cast<_Float16*>(XB1 + L.xb_bytes / 4);
+    _Float16* const Gl = Gh + RT * GP;
+    float* const RS = reinterpret_cast<float*>(reinterpret_cast<char*>(Gh) + L.g_bytes);   // [RT][8]
+    float* const CST = RS + RT * 8;                                // [64][4]  1/|c|, kappa, |s|, |s|^2 of every slot
+    float* const RED = CST + NC * 4;                               // [32]
+    int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
+    float* const KJ = reinterpret_cast<float*>(Gh);                // finish: KJ_j rows [8][D] (G images are dead then)
+    _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: transposed centroid stage [hi, lo][D][8]
+
+    const int N = p.N, M = p.M, NM = N * M;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
+    Team2Flags* const flags = reinterpret_cast<Team2Flags*>(ctl + 1);
+    const TeamId id = team_form(ctl, SH);
+    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the gated launch takes over
+        __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (id.team < 0) return;
+    Team2Flags* const fl = flags + id.team;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
+        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * L.stride, (unsigned)L.stride);
+
+    const int spm = L.spm;
+    const int j0 = id.member * spm;                    // first speaker of this member
+    const int my_spm = max(0, min(spm, N - j0));
+    const int R_my = my_spm * M;
+    const bool has_spk = wid < my_spm;
+    const int j = j0 + wid;                            // this wave's speaker (if has_spk)
+    const int kslot = 8 * id.member + wid;             // ... and the slot every wave is responsible for in A
+    const int rbase = wid * M;                         // first row of that speaker in the images
+
+    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
+    const float fM = (float)M, inv_m1 = 1.0f / (float)(M - 1);
+    const bool contrast = p.variant == 1;
+    const bool want_grad = p.dE != nullptr;
+    const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
+
+    // rows of the ET images that never receive an embedding stay zero (they are contracted over in GC)
+    for (int i = tid; i < RT * P / 8; i += 512) {
+        reinterpret_cast<float4*>(ETh)[i] = zero4();
+        reinterpret_cast<float4*>(ETl)[i] = zero4();
+    }
+    for (int i = tid; i < RT * 2; i += 512) reinterpret_cast<float4*>(RS)[i] = zero4();   // rows without an embedding
+    __syncthreads();
+
+    float4 rowv[MR];            // this wave's rows of the batch about to start
+    float4 held[NTI][RBMAX];    // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..  (GE -> next FINISH)
+    float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                     (S -> next FINISH)
+    float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
+    float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTI; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RBMAX; ++rb) held[i][rb] = zero4();
+
+#define GE2E_T2_LOAD_ROWS(BI)                                                                            \
+    do {                                                                                                 \
+        int lq_ = lane;                                                                                  \
+        asm volatile("" : "+v"(lq_));                                                                    \
+        const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                  \
+        const bool on_ = has_spk && (BI) < p.B;                                                          \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
+            rowv[i] = bload4<AUX_NT>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+    } while (0)
+    // lane-derived indices are re-derived inside each phase from an opaque copy of the lane id (kept out of the
+    // loop-invariant set: hoisted they spill, and a scratch reload queues behind every VMEM operation in flight)
+#define GE2E_T2_LANE()                                                  \
+    int lv_ = lane;                                                     \
+    asm volatile("" : "+v"(lv_));                                       \
+    const int l15 = lv_ & 15, q = lv_ >> 4, d4 = 4 * lv_;               \
+    const bool dact = d4 < D;                                           \
+    (void)l15; (void)q; (void)d4; (void)dact
+
+    GE2E_PROF_DECL(12)
+    GE2E_T2_LOAD_ROWS(id.team);
+    int wslot = 0;
+    bool failed = false;
+    for (int seq = 0;; ++seq) {
+        const int bi = id.team + seq * id.nct;          // batch started in this iteration
+        const bool have_cur = bi < p.B, have_prev = seq > 0;
+        if (!have_cur && !have_prev) break;
+        const int buf = seq & 1, pbuf = buf ^ 1;
+        const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
+                                                       want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
+        cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
+
+        // ===== A(cur): own rows -> ET images; unit centroid -> team (row-major and staged for the k-group form) =====
+        if (have_cur) {
+            GE2E_T2_LANE();
+            float4 s = zero4();
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
+            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float sq = wave_sum(dot4(c, c));
+            const float ss = wave_sum(dot4(s, s));
+            float rn, kap;
+            unit_stats(sq, eps_cos, rn, kap);
+            if (!has_spk) { rn = 0.f; kap = 0.f; }     // slots without a speaker publish zero rows
+            cj_cur = has_spk ? scale4(c, rn) : zero4();
+            rn_cur = rn; kap_cur = kap;
+            h4 hi, lo;
+            split4(scale4(cj_cur, kSplitScale), hi, lo);
+            {   // row-major image row of slot kslot: D hi halfs, then D lo halfs
+                const unsigned vh = dact ? (unsigned)d4 * 2u : OOB;
+                const unsigned o = L.chr[buf] + (unsigned)kslot * ROWB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + o, 0, GE2E_T2_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + o + 2u * D, 0, GE2E_T2_ST_AUX);
+            }
+            if (dact) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    STG[(d4 + e) * 8 + wid] = hi[e];
+                    STG[(D + d4 + e) * 8 + wid] = lo[e];
+                }
+            }
+            // 1/max(|c|,eps), kappa, |s_j| (s_j = c-hat_j * that), |s_j|^2
+            bstore4<GE2E_T2_ST_AUX>(rsX, lane == 0 ? L.cst[buf] + (unsigned)kslot * 16u : OOB,
+                    make_float4(rn, kap, has_spk ? fM / rn : 0.f, has_spk ? ss : 0.f));
+            if (has_spk) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    if (i < M) {
+                        const float4 e = rowv[i];
+                        const float ee = wave_sum(dot4(e, e));
+                        float rne, ke;
+                        unit_stats_fast(ee, eps_cos, rne, ke);
+                        if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));
+                        if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, 0.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d)
+            const float4 v = *reinterpret_cast<const float4*>(STG + tid * 8);
+            bstore4<GE2E_T2_ST_AUX>(rsX, L.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, v);
+        }
+        // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+#if GE2E_T2_RELEASE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            if (have_prev) add_agent(&fl->c2, 1u);
+            if (have_cur) add_agent(&fl->c1, 1u);
+        }
+        GE2E_PROF(0);
+
+        // ===== B(cur): centroid fragments -> registers ==============================================================
+        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
+        h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
+        if (have_cur) {
+            if (!team2_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4, wslot)) { failed = true; break; }
+            GE2E_T2_LANE();
+            const unsigned oa = L.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) {
+                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
+                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
+            }
+            if (want_grad) {
+#pragma unroll
+                for (int i = 0; i < NTI; ++i) {
+                    const int dt = wid + 8 * i;
+                    const bool on = dt < NT;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const unsigned o = L.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
+                        ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
+                        ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
+                    }
+                }
+            }
+        }
+#ifdef GE2E_T2_DEBUG
+        if (have_cur) {
+            unsigned cx = 0, cg = 0;
+            for (int s = 0; s < NCH; ++s) for (int h = 0; h < 2; ++h) cx ^= t2_x4(__builtin_bit_cast(float4, xa[s][h])) * (unsigned)(2 * s + h + 1);
+            if (want_grad) for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h)
+                cg ^= t2_x4(__builtin_bit_cast(float4, ga[i][s2][h])) * (unsigned)(4 * i + 2 * s2 + h + 1);
+            T2_DBG(bi, 0, cx); T2_DBG(bi, 1, cg);
+        }
+#endif
+        float4 cstv = zero4();
+        if (have_cur && tid < NC) cstv = bload4<AUX_L2>(rsX, L.cst[buf] + (unsigned)tid * 16u, 0);
+        GE2E_PROF(1);
+
+        // ===== FINISH(prev): batch scalars; own speaker's gC -> KJ_j; the held rows of dE become complete ===========
+        if (have_prev) {
+            if (!team2_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4, wslot)) { failed = true; break; }
+            GE2E_PROF(2);
+            if (id.member == 0 && tid == 0) {
+                float l = 0.f, a = 0.f, c = 0.f;
+                for (int m = 0; m < TEAM; ++m) {
+                    const float4 v = bload4<AUX_L2>(rsX, L.sc[pbuf] + (unsigned)m * 16u, 0);
+                    l += v.x; a += v.y; c += v.z;
+                }
+                if (p.loss) p.loss[bi - id.nct] = l;
+                if (p.dw) p.dw[bi - id.nct] = a;
+                if (p.db) p.db[bi - id.nct] = c;
+            }
+            if (want_grad) {
+                GE2E_T2_LANE();
+                if (has_spk) {
+                    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
+                    float4 part[TEAM];
+#pragma unroll
+                    for (int m = 0; m < TEAM; ++m)
+                        part[m] = bload4<AUX_L2>(rsX, vrow + L.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
+                    float4 gsum = part[0];
+#pragma unroll
+                    for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+                    // every partial of this speaker has been read: the single gC buffer may be rewritten
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) add_agent(&fl->c3, 1u);
+                    T2_DBG(bi - id.nct, 2, t2_x4(gsum)); T2_DBG(bi - id.nct, 3, t2_x4(kjp)); T2_DBG(bi - id.nct, 4, t2_x4(cj_prev));
+                    gsum = scale4(gsum, w * kSplitInv2);
+                    const float coefc = wave_sum(dot4(gsum, cj_prev));
+                    const float f = kap_prev * coefc, sc = rn_prev / fM;
+                    if (dact)
+                        *reinterpret_cast<float4*>(KJ + wid * D + d4) =
+                            make_float4((gsum.x - f * cj_prev.x) * sc + kjp.x, (gsum.y - f * cj_prev.y) * sc + kjp.y,
+                                        (gsum.z - f * cj_prev.z) * sc + kjp.z, (gsum.w - f * cj_prev.w) * sc + kjp.w);
+                }
+                __syncthreads();
+                // dE_r = held part + KJ_{speaker of r}: two or three speakers per 16-row block
+#pragma unroll
+                for (int i = 0; i < NTI; ++i) {
+                    const int dt = wid + 8 * i;
+#pragma unroll
+                    for (int rb = 0; rb < RBMAX; ++rb) {
+                        if (rb < RB) {
+                            const int r = 16 * rb + l15;
+                            const int loc = min((r * L.mul_m) >> 16, 7);
+                            const float4 kj = *reinterpret_cast<const float4*>(KJ + loc * D + min(16 * dt, D - 16) + 4 * q);
+                            const bool ok = r < R_my && dt < NT;
+                            const float4 h = held[i][rb];
+                            T2_DBG(bi - id.nct, 5 + rb, t2_x4(h));
+                            bstore4<AUX_NT>(rsGp, ok ? (unsigned)((j0 * M + r) * D + 16 * dt + 4 * q) * 4u : OOB,
+                                            make_float4(h.x + kj.x, h.y + kj.y, h.z + kj.z, h.w + kj.w));
+                        }
+                    }
+                }
+            }
+            GE2E_PROF(3);
+        }
+        if (!have_cur) break;
+
+        GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under X .. GE
+
+        // ===== X(cur): X[r][slot] over this wave's K half -> LDS ====================================================
+        {
+            GE2E_T2_LANE();
+            float* const XBk = khX ? XB1 : XB0;
+#pragma unroll
+            for (int rb = 0; rb < RBMAX; ++rb) {
+                if (rb < RB) {
+                    f32x4 acc = acc_zero4();
+                    const int off_b = (16 * rb + l15) * P + 32 * khX * NCH + 8 * q;
+#pragma unroll
+                    for (int s = 0; s < NCH; ++s)
+                        mfma16x3(acc, xa[s][0], xa[s][1], frag_row(ETh + off_b + 32 * s), frag_row(ETl + off_b + 32 * s));
+                    T2_SETTLE16(acc);
+                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]
+                    *reinterpret_cast<float4*>(XBk + (16 * rb + l15) * XP + 16 * tX + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
+        }
+        __syncthreads();
+        GE2E_PROF(4);
+
+        // ===== S(cur): leave-one-out statistics, S, loss, dL/dS -> G images, row coefficients =======================
+        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        {
+            GE2E_T2_LANE();
+            const int c4 = 4 * l15;
+            const int nval = max(0, min(spm, N - (l15 >> 1) * spm));   // valid slots of the member this lane's columns belong to
+            for (int pi = wid; 4 * pi < RT; pi += 8) {
+                const int r = 4 * pi + q;
+                const bool rv = r < R_my;
+                const int loc = min((r * L.mul_m) >> 16, 7);
+                const int ko = 8 * id.member + loc;                    // own-speaker slot of this row
+                const float4 x0 = *reinterpret_cast<const float4*>(XB0 + r * XP + c4);
+                const float4 x1 = *reinterpret_cast<const float4*>(XB1 + r * XP + c4);
+                const float xs[4] = {x0.x + x1.x, x0.y + x1.y, x0.z + x1.z, x0.w + x1.w};
+                const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
+                const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee
+                const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
+                const float rne = rv ? rs0.x : 0.f, ke = rs0.y, ee = rs0.z;
+                const float rne1 = rv ? rs0.x : 1.0f;
+                const float es = xo * cs.z / rne1;               // e . s_j
+                const float eu = (es - ee) * inv_m1;
+                const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+                float rnu, ku;
+                unit_stats_fast(uu, eps_cos, rnu, ku);
+                const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+                const float sjj = w * (cosd + eps) + bias;
+                float c0[4], sv[4], g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c4 + e;
+                    c0[e] = (k == ko) ? cosd : xs[e] * kSplitInv2;
+                    sv[e] = ((k & 7) < nval) ? w * (c0[e] + eps) + bias : -INFINITY;
+                }
+                float per;
+                if (!contrast) {
+                    float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+                    mx = fmaxf(row16_max(mx), log_eps);
+                    float zoff = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g[e] = __expf(sv[e] - mx);   // exp(-inf) = 0 for unused slots
+                        if (c4 + e != ko) zoff += g[e];
+                    }
+                    zoff = row16_sum(zoff) + __expf(log_eps - mx);
+                    const float z = zoff + __expf(sjj - mx);
+                    per = (mx - sjj) + __logf(z);
+                    const float rz = 1.0f / z;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = (c4 + e == ko) ? -zoff * rz : g[e] * rz;   // 1 - p_jj = z_off / z
+                } else {
+                    float best = -INFINITY; int besti = 0x7fffffff;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = c4 + e;
+                        if (k != ko && sv[e] > best) { best = sv[e]; besti = k; }
+                    }
+                    row16_argmax(best, besti);
+                    const float pos = 1.0f / (1.0f + __expf(-sjj));
+                    const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
+                    per = 1.0f - pos + neg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = c4 + e;
+                        g[e] = (k == ko) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+                    }
+                }
+                float coef = 0.f, ad0 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c4 + e;
+                    if (!rv || (k & 7) >= nval) g[e] = 0.f;
+                    dw_acc += g[e] * (c0[e] + eps);
+                    db_acc += g[e];
+                    coef += g[e] * c0[e];           // (dL/d e-hat) . e-hat / w, own-speaker term included
+                    if (k == ko) { ad0 = g[e]; g[e] = 0.f; }
+                }
+                coef = w * row16_sum(coef);
+                ad0 = row16_sum(ad0);               // dL/dS on the own-speaker column
+                if (rv && l15 == 0) {
+                    loss_acc += per;
+                    if (p.per) p.per[(size_t)bi * NM + j0 * M + r] = per;
+                }
+                if (want_grad) {
+                    // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
+                    // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
+                    // of s_j (o, in units of ra) without dividing by w
+                    const float ad = w * ad0;
+                    const float rho = rnu * inv_m1;
+                    const float c2_0 = rho * (ad0 * rne1 + ad0 * ku * cosd * rnu * inv_m1);
+                    const float c2 = w * c2_0;
+                    const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
+                    const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
+                    const float beta = -ad * rnu * ku * cosd * rho;
+                    const float o = rv ? c2_0 * cs.z / rne1 : 0.f;
+                    // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
+                    // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
+                    const float lam = cs.x / fM * w;
+                    if (l15 == 0)
+                        *reinterpret_cast<float4*>(RS + r * 8 + 4) =
+                            make_float4(rne * (w * kSplitInv2),                                   // ra: of the gE accumulator (2^16)
+                                        rv ? c1 * kSplitInv : 0.f,                                // c1: of the e-hat image value (2^8)
+                                        rv ? (alpha * inv_m1 - lam * o) * kSplitInv : 0.f,        // c3'
+                                        rv ? beta * inv_m1 * cs.z + lam * cs.y * o * xo : 0.f);   // c4' (of c-hat_j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c4 + e == ko) g[e] = o;
+                    put_split4(Gh, Gl, r * GP + c4, make_float4(g[0] * kSplitScale, g[1] * kSplitScale, g[2] * kSplitScale, g[3] * kSplitScale));
+                }
+            }
+        }
+        // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
+        loss_acc = wave_sum(loss_acc);
+        dw_acc = wave_sum(dw_acc);
+        db_acc = wave_sum(db_acc);
+        if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
+        __syncthreads();
+        GE2E_PROF(5);
+        if (tid == 0) {
+            float l = 0.f, a = 0.f, c = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
+            bstore4<GE2E_T2_ST_AUX>(rsX, L.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
+        }
+
+        if (want_grad) {
+            // ===== speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns) ==========
+            kjp = zero4();
+            if (has_spk) {
+                GE2E_T2_LANE();
+                const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
+                const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    if (i < M) {
+                        const float c3 = RS[(rbase + i) * 8 + 6];
+                        const int off = (rbase + i) * P + min(d4, D - 4);
+                        const h4 eh = *reinterpret_cast<const h4*>(ETh + off), el = *reinterpret_cast<const h4*>(ETl + off);
+                        kjp.x = fmaf((float)eh[0], c3, fmaf((float)el[0], c3, kjp.x));
+                        kjp.y = fmaf((float)eh[1], c3, fmaf((float)el[1], c3, kjp.y));
+                        kjp.z = fmaf((float)eh[2], c3, fmaf((float)el[2], c3, kjp.z));
+                        kjp.w = fmaf((float)eh[3], c3, fmaf((float)el[3], c3, kjp.w));
+                    }
+                }
+                kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
+                if (!dact) kjp = zero4();
+            }
+            GE2E_PROF(6);
+
+            // ===== GC: partial gC^T[d][k] = sum_r ET[r][d] G[r][k]; wave: slots 32 kh.., columns 64 sl.. ============
+            {
+                GE2E_T2_LANE();
+                const int kh = wid >> 2, sl = wid & 3;
+                if (64 * sl < D) {
+                    f32x16 gc[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
+                    asm volatile("" : "+v"(gc[0]), "+v"(gc[1]));
+                    for (int s = 0; s < RB; ++s) {
+                        const h8 gh = frag_tr(Gh, GP, 16 * s, 32 * kh, lv_), gl = frag_tr(Gl, GP, 16 * s, 32 * kh, lv_);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            mfma32x3(gc[b], frag_tr(ETh, P, 16 * s, 64 * sl + 32 * b, lv_),
+                                     frag_tr(ETl, P, 16 * s, 64 * sl + 32 * b, lv_), gh, gl);
+                    }
+                    T2_SETTLE32(gc[0], gc[1]);
+                    // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
+                    bool ok = true;
+                    if (seq > 0) {
+                        int okv = 1;
+                        if (lv_ == 0) okv = spin_until(&fl->c3, (unsigned)(N * seq), ctl) ? 1 : 0;
+                        ok = __builtin_amdgcn_readfirstlane(okv) != 0;
+                    }
+                    if (ok) {
+                        // lane (k = l31, h): registers 4 g .. 4 g + 3 = columns 32 b + 8 g + 4 h + 0..3 of slot 32 kh + l31
+                        const int l31 = lv_ & 31, h = lv_ >> 5;
+                        const unsigned ob = L.gc + (unsigned)((id.member * NC + 32 * kh + l31) * D + 64 * sl + 4 * h) * 4u;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4)
+                                bstore4<GE2E_T2_ST_AUX>(rsX, ob + (unsigned)(32 * b + 8 * g4) * 4u,
+                                        make_float4(gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]));
+                    }
+                }
+            }
+            GE2E_PROF(7);
+
+            // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
+            {
+                GE2E_T2_LANE();
+#pragma unroll
+                for (int rb = 0; rb < RBMAX; ++rb) {
+                    if (rb < RB) {
+                        const int r = 16 * rb + l15;
+                        h8 gb[2][2];
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            gb[s2][0] = frag_row(Gh + r * GP + 32 * s2 + 8 * q);
+                            gb[s2][1] = frag_row(Gl + r * GP + 32 * s2 + 8 * q);
+                        }
+                        const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            const int dt = wid + 8 * i;
+                            if (dt < NT) {
+                                f32x4 acc = acc_zero4();
+                                mfma16x3(acc, ga[i][0][0], ga[i][0][1], gb[0][0], gb[0][1]);
+                                mfma16x3(acc, ga[i][1][0], ga[i][1][1], gb[1][0], gb[1][1]);
+                                T2_SETTLE16(acc);
+                                // lane (r = l15, q) holds gE[r][16 dt + 4 q + i]
+                                const int eo = r * P + 16 * dt + 4 * q;
+                                const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo);
+                                held[i][rb] = make_float4(fmaf((float)eh[0], rc.y, fmaf((float)el[0], rc.y, acc[0] * rc.x)),
+                                                          fmaf((float)eh[1], rc.y, fmaf((float)el[1], rc.y, acc[1] * rc.x)),
+                                                          fmaf((float)eh[2], rc.y, fmaf((float)el[2], rc.y, acc[2] * rc.x)),
+                                                          fmaf((float)eh[3], rc.y, fmaf((float)el[3], rc.y, acc[3] * rc.x)));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // the next iteration's A rewrites the ET images and the stage inside the X block
+        __syncthreads();
+#ifdef GE2E_T2_DEBUG
+        if (g_t2_dump && seq == 0) {   // everything GE read, dumped after the barrier (does not disturb GE itself)
+            unsigned* dst = g_t2_dump + ((size_t)bi * 8 + id.member) * 32768;   // 128 KB per (batch, member)
+            const unsigned* src = reinterpret_cast<const unsigned*>(smem_f);
+            const int n_et = RT * P;            // dwords of both ET images
+            for (int i = tid; i < n_et; i += 512) dst[i] = src[i];
+            const unsigned* gsrc = reinterpret_cast<const unsigned*>(Gh);
+            for (int i = tid; i < RT * GP; i += 512) dst[8192 + i] = gsrc[i];
+            const unsigned* rsrc_ = reinterpret_cast<const unsigned*>(RS);
+            for (int i = tid; i < RT * 8; i += 512) dst[12288 + i] = rsrc_[i];
+            for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h) {
+                const uint4 v = __builtin_bit_cast(uint4, ga[i][s2][h]);
+                unsigned* d = dst + 13312 + ((i * 4 + s2 * 2 + h) * 512 + tid) * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+        }
+#endif
+        GE2E_PROF(8);
+    }
+    if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GE2E_PROF_FLUSH(12)
+#undef GE2E_T2_LOAD_ROWS
+#undef GE2E_T2_LANE
+}
+
+#ifdef GE2E_T2_DEBUG
+extern "C" void ge2e_debug_set_t2(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_dbg), &p, sizeof(p)); }
+extern "C" void ge2e_debug_set_t2_dump(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_dump), &p, sizeof(p)); }
+#endif
+// ---------------------------------------------------------------------------------------------
+template <int NCH, int MR>
+static hipError_t launch_nch(Problem& p, Team2Ws& L, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(ge2e_team2_kernel<NCH, MR>);
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
+    if (err != hipSuccess) return err;
+    err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
+    if (err != hipSuccess) return err;
+    // Every workgroup must be resident (they wait for each other): grid <= resident capacity is what a cooperative
+    // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
+    // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
+    // behind it redoes every batch with the one-workgroup-per-batch kernel.
+    int nb = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
+    if (err != hipSuccess) return err;
+    const int grid = team2_grid(p.B);
+    if (nb < 1 || grid > nb * team2_cu_count()) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((ge2e_team2_kernel<NCH, MR>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_team2(const Problem& p_in, hipStream_t stream) {
+    Problem p = p_in;
+    Team2Ws L = team2_layout(p.N, p.M, p.D);
+    hipError_t err;
+    if (p.M <= 10) {
+        switch (p.D / 64) {
+            case 1: err = launch_nch<1, 10>(p, L, stream); break;
+            case 2: err = launch_nch<2, 10>(p, L, stream); break;
+            case 3: err = launch_nch<3, 10>(p, L, stream); break;
+            default: err = launch_nch<4, 10>(p, L, stream); break;
+        }
+    } else {
+        switch (p.D / 64) {
+            case 1: err = launch_nch<1, 16>(p, L, stream); break;
+            case 2: err = launch_nch<2, 16>(p, L, stream); break;
+            case 3: err = launch_nch<3, 16>(p, L, stream); break;
+            default: err = launch_nch<4, 16>(p, L, stream); break;
+        }
+    }
+    if (err != hipSuccess) return err;
+    // gated fall-back: runs only if the team kernel raised its abort word (workgroups exit at once otherwise)
+    Problem f = p_in;
+    const TeamCtl* ctl = reinterpret_cast<const TeamCtl*>(p_in.ws);
+    f.gate = &ctl->abort_;
+    f.grid_cap = TEAM2_FALLBACK_GRID;
+    f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
+                                    align_up(L.head_bytes + (size_t)(team2_grid(p.B) / TEAM) * L.stride, 256));
+    return launch_fused_split(f, stream);
+}
+
+}  // namespace ge2e

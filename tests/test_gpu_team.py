@@ -20,12 +20,16 @@ def GF():
     return functional
 
 
-def test_many_batches_per_team_full_size(GF):
+TEAM_IMPLS = ("team", "team2")
+
+
+@pytest.mark.parametrize("impl", TEAM_IMPLS)
+def test_many_batches_per_team_full_size(GF, impl):
     """B = 150 at the metric shape: 32 teams, 4-5 batches each -> every stage of the pipeline
     (prologue, steady state, drain) runs; all outputs written; matches fused_split and the oracle."""
     B, N, M, D = 150, 64, 10, 256
     E = orc.synth_embeddings((B, N, M, D), "unit", seed=21)
-    ot = run_hip(GF, E, 10.0, -5.0, impl="team")
+    ot = run_hip(GF, E, 10.0, -5.0, impl=impl)
     of = run_hip(GF, E, 10.0, -5.0, impl="fused_split")
     assert not np.isnan(ot["dE"]).any() and not np.isnan(ot["loss"]).any() and not np.isnan(ot["per"]).any()
     assert np.allclose(ot["loss"], of["loss"], rtol=2e-6)
@@ -42,13 +46,14 @@ def test_many_batches_per_team_full_size(GF):
 
 @pytest.mark.parametrize("shape", [(40, 23, 7, 128), (70, 9, 5, 64), (3, 32, 16, 64), (33, 64, 2, 192), (5, 17, 4, 256)])
 @pytest.mark.parametrize("variant", ["softmax", "contrast"])
-def test_uneven_members(GF, shape, variant):
+@pytest.mark.parametrize("impl", TEAM_IMPLS)
+def test_uneven_members(GF, shape, variant, impl):
     """N not a multiple of 8 (members with fewer or no speakers), M up to 16, every supported D."""
     B, N, M, D = shape
-    assert GF.resolve_impl(B, N, M, D, variant, "team") == "team"
+    assert GF.resolve_impl(B, N, M, D, variant, impl) == impl
     E = orc.synth_embeddings(shape, "raw", seed=sum(shape))
     ref = orc.closed_form(E, 6.0, -1.5, variant=variant)
-    o = run_hip(GF, E, 6.0, -1.5, variant, "team")
+    o = run_hip(GF, E, 6.0, -1.5, variant, impl)
     assert np.allclose(o["loss"], ref["loss"], rtol=2e-5), variant
     assert np.allclose(o["per"], ref["per"], rtol=1e-4, atol=1e-4)
     assert np.allclose(o["dw"], ref["dw"], rtol=1e-4, atol=1e-4)
@@ -57,12 +62,13 @@ def test_uneven_members(GF, shape, variant):
         assert rel_fro(o["dE"][i], ref["dE"][i]) < 2e-5, (i, variant)
 
 
-def test_forward_only(GF):
+@pytest.mark.parametrize("impl", TEAM_IMPLS)
+def test_forward_only(GF, impl):
     B, N, M, D = 37, 64, 10, 256
     E = orc.synth_embeddings((B, N, M, D), "clustered", seed=2)
     e = torch.as_tensor(E, device="cuda:0")
     w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
-    o = GF.loss_fwd_bwd(e, w, b, impl="team", need_grad=False, need_per=True)
+    o = GF.loss_fwd_bwd(e, w, b, impl=impl, need_grad=False, need_per=True)
     torch.cuda.synchronize()
     assert o.dE is None
     ref = orc.closed_form(E, 10.0, -5.0, want_grad=False)
@@ -78,7 +84,8 @@ def test_auto_uses_team_for_few_batches(GF):
         GF.resolve_impl(1, 64, 20, 256, "softmax", "team")                        # M > 16
 
 
-def test_hand_off_protocol_stress(GF):
+@pytest.mark.parametrize("impl", TEAM_IMPLS)
+def test_hand_off_protocol_stress(GF, impl):
     """400 launches of a multi-batch-per-team problem: every launch bitwise equal to the first
     (a stale or torn read in the L2 hand-offs would show as a different bit pattern somewhere)."""
     B, N, M, D = 72, 64, 10, 256
@@ -86,13 +93,13 @@ def test_hand_off_protocol_stress(GF):
     dev = torch.device("cuda:0")
     e = torch.as_tensor(E, device=dev)
     w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
-    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", "team"), dev)
+    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", impl), dev)
     first = None
     for it in range(400):
         out = GF.LossOutputs(loss=torch.full((B,), float("nan"), device=dev), per=None,
                              dE=torch.full((B, N, M, D), float("nan"), device=dev),
                              dw=torch.full((B,), float("nan"), device=dev), db=torch.full((B,), float("nan"), device=dev))
-        GF.loss_fwd_bwd(e, w, b, impl="team", out=out, workspace=ws)
+        GF.loss_fwd_bwd(e, w, b, impl=impl, out=out, workspace=ws)
         if first is None:
             torch.cuda.synchronize()
             first = (out.loss.clone(), out.dE.clone(), out.dw.clone(), out.db.clone())
