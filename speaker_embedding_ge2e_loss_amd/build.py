@@ -38,17 +38,67 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Per-source compile flags.  ge2e_team2.hip: no SLP vectorisation -- hipcc packs the fp32 epilogue arithmetic that
+# follows its (inline-asm) MFMA chains into v_pk_mul_f32 / v_pk_fma_f32, and on gfx950 those lost the fused-in term in
+# the low register of a pair, lanes 48..63, in up to 70 % of the launches (hazards).
+EXTRA_FLAGS = {"ge2e_team2.hip": ["-fno-slp-vectorize"]}
+OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
+
+
+def _compile_one(args):
+    src, obj, verbose = args
+    cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", "-Wall", "-Wno-unused-function",
+           f"-I{INCLUDE}"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-o", obj, src]
+    if verbose:
+        print("[ge2e build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every csrc/*.hip into one shared object.  Returns its path."""
+    """Compile every csrc/*.hip to an object (in parallel, only the stale ones) and link one shared object."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", "-o", LIB_PATH + ".tmp"] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(d) for d in glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+                + [os.path.abspath(__file__)])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((src, obj, verbose))
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(_compile_one, jobs))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
         print("[ge2e build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
+
+
+def build_variant(out_path: str, defs: list[str], verbose: bool = False) -> str:
+    """Diagnostic / experiment builds (tools/): the same per-source flags plus extra -D definitions, objects in a
+    directory of their own, nothing shared with the product library."""
+    from concurrent.futures import ThreadPoolExecutor
+    odir = out_path + ".obj"
+    os.makedirs(odir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
+        cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", f"-I{INCLUDE}"] + list(defs) + \
+            EXTRA_FLAGS.get(os.path.basename(src), []) + ["-o", obj, src]
+        if verbose:
+            print("[ge2e build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, stderr=None if verbose else subprocess.DEVNULL)
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, sources()))
+    subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out_path] + objs, check=True)
+    shutil.rmtree(odir, ignore_errors=True)
+    return out_path
 
 
 if __name__ == "__main__":

@@ -31,11 +31,11 @@
 namespace ge2e {
 
 #ifdef GE2E_T2_DEBUG
-__device__ unsigned* g_t2_dbg = nullptr;   // [B][8 members][16 items][512 threads]
+__device__ unsigned* g_t2_dbg = nullptr;   // [B][8 members][32 items][512 threads]
 __device__ unsigned* g_t2_dump = nullptr;  // [B][8 members][32768] dwords
 #define T2_DBG(batch, item, val)                                                                              \
     do {                                                                                                      \
-        if (g_t2_dbg) g_t2_dbg[(((size_t)(batch) * 8 + id.member) * 16 + (item)) * 512 + threadIdx.x] = (val); \
+        if (g_t2_dbg) g_t2_dbg[(((size_t)(batch) * 8 + id.member) * 32 + (item)) * 512 + threadIdx.x] = (val); \
     } while (0)
 __device__ __forceinline__ unsigned t2_x4(const float4& v) {
     return __float_as_uint(v.x) ^ (__float_as_uint(v.y) * 3u) ^ (__float_as_uint(v.z) * 5u) ^ (__float_as_uint(v.w) * 7u);
@@ -43,6 +43,7 @@ __device__ __forceinline__ unsigned t2_x4(const float4& v) {
 #else
 #define T2_DBG(batch, item, val)
 #endif
+
 
 namespace {
 
@@ -97,6 +98,20 @@ __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& 
         unit_stats(sq, eps_cos, rn, kappa);
     }
 }
+// x / max(|x|, eps) bookkeeping without a branch: rn = 1 / max(|x|, eps), kappa = clamped / true norm (0 for a
+// zero vector), nc = max(|x|, eps).  v_rsq_f32 + one Newton step instead of sqrt and two IEEE divisions.
+__device__ __forceinline__ void unit_stats_bf(float sq, float eps_cos, float eps_cos2, float& rn, float& kappa, float& nc) {
+    const float sqc = fmaxf(sq, eps_cos2);
+    float r = __builtin_amdgcn_rsqf(sqc);
+    r = r * (1.5f - 0.5f * sqc * r * r);
+    rn = r;
+    nc = sqc * r;
+    kappa = sq >= eps_cos2 ? 1.0f : (sq > 1e-36f ? eps_cos * __builtin_amdgcn_rsqf(sq) : 0.0f);
+}
+__device__ __forceinline__ float rcp_nr(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
 __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
     h4 hi, lo;
     split4(x, hi, lo);
@@ -110,7 +125,10 @@ __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, i
 // can start late, the LDS read lands first, and the rows of the LAST pass (accumulator lanes 48..63) pick up the new
 // fragment bits instead of the partial sum.  Found with per-thread checksums of two identical launches: every input of
 // GE identical, `held` different in lanes q = 3 only, in 5-75 % of the launches depending on how long the phase ran.
-// A tied accumulator is only ever written by the (in-order) matrix pipe.  hipcc pads nothing around asm, so the wait
+// A tied accumulator is only ever written by the (in-order) matrix pipe.  Each accumulator's MFMAs are issued BACK TO
+// BACK: with a second, independent chain interleaved (distance 2 between dependent MFMAs) whole 16 x 16 tiles came out
+// wrong whenever the SIMD's other wave was not issuing MFMAs of the same kind at the same time (first / last row block
+// of GE); hipcc would have padded that case with wait states, asm gets none.  hipcc pads nothing around asm, so the wait
 // states between the last MFMA of a chain and the first read of its result are spelled out (T2_SETTLE*).
 __device__ __forceinline__ void mfma16(f32x4& acc, const h8& a, const h8& b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
@@ -125,11 +143,26 @@ __device__ __forceinline__ void mfma16x3(f32x4& acc, const h8& ah, const h8& al,
 __device__ __forceinline__ void mfma32x3(f32x16& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
     mfma32(acc, ah, bh); mfma32(acc, ah, bl); mfma32(acc, al, bh);
 }
-#define T2_SETTLE16(acc) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc))                  /* 16x16x32: 8 passes  */
+// ... and the same blindness covers the OPERANDS: hipcc does not know that the asm reads A / B for several cycles after
+// issue (a dependent MFMA starts only when its predecessor's sum is there), so it happily reuses a fragment register
+// for a VALU temporary one instruction later (seen: v_add_u32 v6 right behind `v_mfma .., v[6:9], ..`), and the MFMA
+// multiplies with the temporary.  Every fragment register of a chain is therefore kept live (an empty asm that
+// "reads" it) until the chain's settle has passed.
+#define T2_KEEP(x) asm volatile("" :: "v"(x))
+#define T2_SETTLE16_1(a0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0))
+#define T2_SETTLE16_2(a0, a1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))            /* 16x16x32: 8 passes  */
+#define T2_SETTLE16_4(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 #define T2_SETTLE32(a0, a1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))  /* 32x32x16: 16 passes */
+// results of an EARLIER chain may be read once a whole later chain has been issued behind it (the pipe is in order);
+// this empty statement keeps the compiler from moving such a read above the later chain's (volatile) MFMAs
+#define T2_AFTER_1(a0) asm volatile("" : "+v"(a0))
+#define T2_AFTER_2(a0, a1) asm volatile("" : "+v"(a0), "+v"(a1))
 __device__ __forceinline__ f32x4 acc_zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    asm volatile("" : "+v"(z));    // a register, not the inline constant 0: the chain starts in its final home
+    // a register, not the inline constant 0: the chain starts in its final home.  hipcc pads nothing around asm, so the
+    // wait states between these VALU writes and an (asm) MFMA reading them as SrcC are spelled out here: without them
+    // whole accumulator tiles started from the register's OLD contents whenever the wave issued back to back
+    asm volatile("s_nop 4" : "+v"(z));
     return z;
 }
 
@@ -170,10 +203,9 @@ Team2Ws team2_layout(int N, int M, int D) {
     L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(Team2Flags), 256);
     const int P = D + 16;
     const size_t et = (size_t)2 * L.rt * P * 2;
-    size_t xb = (size_t)L.rt * XP * 4;                 // X half-block; the second one also stages the transposed centroid
-    if (xb < (size_t)D * 32) xb = (size_t)D * 32;
-    size_t g = (size_t)2 * L.rt * GP * 2;              // G images; also the KJ rows [8][D] of the finish phase
-    if (g < (size_t)8 * D * 4) g = (size_t)8 * D * 4;
+    size_t xb = (size_t)L.rt * XP * 4;                 // X half-blocks; the first also holds the KJ rows [8][D] of phase F,
+    if (xb < (size_t)8 * D * 4) xb = (size_t)8 * D * 4;   // the second stages the transposed centroid [2][D][8] halfs
+    const size_t g = (size_t)2 * L.rt * GP * 2;        // G images
     L.xb_bytes = (unsigned)xb;
     L.g_bytes = (unsigned)g;
     L.lds_bytes = et + 2 * xb + g + (size_t)(L.rt * 8 + NC * 4 + 32 + 16) * sizeof(float);
@@ -204,7 +236,9 @@ size_t team2_workspace_bytes(int B, int N, int M, int D) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MR>  // D = 64 * NCH; MR >= M rows of a speaker are prefetched into registers
+// D = 64 * NCH; MR >= M rows of a speaker are prefetched into registers; RBT > 0: the member's images have exactly
+// RBT 16-row blocks (compile-time trip counts for the metric shape), RBT == 0: L.rt / 16 at run time.
+template <int NCH, int MR, int RBT, bool CONTRAST>
 __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
@@ -212,7 +246,18 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     constexpr unsigned ROWB = D * 4;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
     constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
-    const int RT = L.rt, RB = RT / 16;
+    constexpr int RBC = RBT ? RBT : RBMAX;
+    const int RB = RBT ? RBT : L.rt / 16;
+    const int RT = 16 * RB;
+#ifndef GE2E_T2_CTMASK
+#define GE2E_T2_CTMASK 31
+#endif
+    int RBr = RB;                         // the same number, opaque to the compiler
+    asm volatile("" : "+s"(RBr));
+#define CT_X (RBT && (GE2E_T2_CTMASK & 1))
+#define CT_S (RBT && (GE2E_T2_CTMASK & 2))
+#define CT_DE (RBT && (GE2E_T2_CTMASK & 4))
+#define CT_GC (RBT && (GE2E_T2_CTMASK & 8))
     _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
     _Float16* const ETl = ETh + RT * P;
     float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
@@ -223,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     float* const CST = RS + RT * 8;                                // [64][4]  1/|c|, kappa, |s|, |s|^2 of every slot
     float* const RED = CST + NC * 4;                               // [32]
     int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
-    float* const KJ = reinterpret_cast<float*>(Gh);                // finish: KJ_j rows [8][D] (G images are dead then)
+    float* const KJ = XB0;                                         // F: KJ_j rows [8][D] (X has been consumed by then)
     _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: transposed centroid stage [hi, lo][D][8]
 
     const int N = p.N, M = p.M, NM = N * M;
@@ -251,11 +296,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     const int rbase = wid * M;                         // first row of that speaker in the images
 
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
-    const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
-    const float fM = (float)M, inv_m1 = 1.0f / (float)(M - 1);
-    const bool contrast = p.variant == 1;
+    const float eps = p.eps, eps_cos = p.eps_cos;
+    const float eps_cos2 = eps_cos * eps_cos;
+    const float fM = (float)M, inv_m = 1.0f / fM, inv_m1 = 1.0f / (float)(M - 1);
     const bool want_grad = p.dE != nullptr;
     const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
+    // softmax in base 2: S2 = S log2(e)
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const float w2 = w * LOG2E, b2 = (w * eps + bias) * LOG2E, leps2 = p.log_eps * LOG2E;
 
     // rows of the ET images that never receive an embedding stay zero (they are contracted over in GC)
     for (int i = tid; i < RT * P / 8; i += 512) {
@@ -266,14 +314,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     __syncthreads();
 
     float4 rowv[MR];            // this wave's rows of the batch about to start
-    float4 held[NTI][RBMAX];    // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..  (GE -> next FINISH)
-    float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                     (S -> next FINISH)
+    float4 held[NTI][RBC];      // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..   (GE -> next iteration)
+    float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                      (F -> next F)
     float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
     float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
 #pragma unroll
     for (int i = 0; i < NTI; ++i)
 #pragma unroll
-        for (int rb = 0; rb < RBMAX; ++rb) held[i][rb] = zero4();
+        for (int rb = 0; rb < RBC; ++rb) held[i][rb] = zero4();
 
 #define GE2E_T2_LOAD_ROWS(BI)                                                                            \
     do {                                                                                                 \
@@ -307,19 +355,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                                                        want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
         cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
 
-        // ===== A(cur): own rows -> ET images; unit centroid -> team (row-major and staged for the k-group form) =====
+        // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
         if (have_cur) {
             GE2E_T2_LANE();
             float4 s = zero4();
 #pragma unroll
             for (int i = 0; i < MR; ++i)
                 if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
-            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float4 c = scale4(s, inv_m);
             const float sq = wave_sum(dot4(c, c));
             const float ss = wave_sum(dot4(s, s));
-            float rn, kap;
-            unit_stats(sq, eps_cos, rn, kap);
-            if (!has_spk) { rn = 0.f; kap = 0.f; }     // slots without a speaker publish zero rows
+            float rn, kap, nc;
+            unit_stats_bf(sq, eps_cos, eps_cos2, rn, kap, nc);
+            if (!has_spk) { rn = 0.f; kap = 0.f; nc = 0.f; }     // slots without a speaker publish zero rows
             cj_cur = has_spk ? scale4(c, rn) : zero4();
             rn_cur = rn; kap_cur = kap;
             h4 hi, lo;
@@ -339,20 +387,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
             }
             // 1/max(|c|,eps), kappa, |s_j| (s_j = c-hat_j * that), |s_j|^2
             bstore4<GE2E_T2_ST_AUX>(rsX, lane == 0 ? L.cst[buf] + (unsigned)kslot * 16u : OOB,
-                    make_float4(rn, kap, has_spk ? fM / rn : 0.f, has_spk ? ss : 0.f));
-            if (has_spk) {
-#pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    if (i < M) {
-                        const float4 e = rowv[i];
-                        const float ee = wave_sum(dot4(e, e));
-                        float rne, ke;
-                        unit_stats_fast(ee, eps_cos, rne, ke);
-                        if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));
-                        if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, 0.f);
-                    }
-                }
-            }
+                                    make_float4(rn, kap, has_spk ? fM * nc : 0.f, has_spk ? ss : 0.f));
         }
         __syncthreads();
         if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d)
@@ -372,238 +407,234 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
         }
         GE2E_PROF(0);
 
-        // ===== B(cur): centroid fragments -> registers ==============================================================
-        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
-        h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
-        if (have_cur) {
-            if (!team2_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4, wslot)) { failed = true; break; }
+        // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
+        if (have_cur && has_spk) {
             GE2E_T2_LANE();
-            const unsigned oa = L.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
 #pragma unroll
-            for (int s = 0; s < NCH; ++s) {
-                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
-                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
-            }
-            if (want_grad) {
-#pragma unroll
-                for (int i = 0; i < NTI; ++i) {
-                    const int dt = wid + 8 * i;
-                    const bool on = dt < NT;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const unsigned o = L.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
-                        ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
-                        ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
-                    }
+            for (int i = 0; i < MR; ++i) {
+                if (i < M) {
+                    const float4 e = rowv[i];
+                    const float ee = wave_sum(dot4(e, e));
+                    float rne, ke, ne;
+                    unit_stats_bf(ee, eps_cos, eps_cos2, rne, ke, ne);
+                    if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));
+                    if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, ne);
                 }
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
         }
-#ifdef GE2E_T2_DEBUG
-        if (have_cur) {
-            unsigned cx = 0, cg = 0;
-            for (int s = 0; s < NCH; ++s) for (int h = 0; h < 2; ++h) cx ^= t2_x4(__builtin_bit_cast(float4, xa[s][h])) * (unsigned)(2 * s + h + 1);
-            if (want_grad) for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h)
-                cg ^= t2_x4(__builtin_bit_cast(float4, ga[i][s2][h])) * (unsigned)(4 * i + 2 * s2 + h + 1);
-            T2_DBG(bi, 0, cx); T2_DBG(bi, 1, cg);
-        }
-#endif
-        float4 cstv = zero4();
-        if (have_cur && tid < NC) cstv = bload4<AUX_L2>(rsX, L.cst[buf] + (unsigned)tid * 16u, 0);
         GE2E_PROF(1);
 
-        // ===== FINISH(prev): batch scalars; own speaker's gC -> KJ_j; the held rows of dE become complete ===========
-        if (have_prev) {
-            if (!team2_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4, wslot)) { failed = true; break; }
-            GE2E_PROF(2);
-            if (id.member == 0 && tid == 0) {
-                float l = 0.f, a = 0.f, c = 0.f;
-                for (int m = 0; m < TEAM; ++m) {
-                    const float4 v = bload4<AUX_L2>(rsX, L.sc[pbuf] + (unsigned)m * 16u, 0);
-                    l += v.x; a += v.y; c += v.z;
-                }
-                if (p.loss) p.loss[bi - id.nct] = l;
-                if (p.dw) p.dw[bi - id.nct] = a;
-                if (p.db) p.db[bi - id.nct] = c;
+        // ===== W: both hand-offs (signalled by every member at the same point) ======================================
+        {
+            int* const wsh = SH + 4 + (wslot & 3);
+            ++wslot;
+            if (tid == 0) {
+                bool ok = true;
+                if (have_cur) ok = spin_until(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl);
+                if (ok && have_prev) ok = spin_until(&fl->c2, (unsigned)(TEAM * seq), ctl);
+                *wsh = ok ? 1 : 0;
             }
-            if (want_grad) {
-                GE2E_T2_LANE();
-                if (has_spk) {
-                    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
-                    float4 part[TEAM];
-#pragma unroll
-                    for (int m = 0; m < TEAM; ++m)
-                        part[m] = bload4<AUX_L2>(rsX, vrow + L.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
-                    float4 gsum = part[0];
-#pragma unroll
-                    for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
-                    // every partial of this speaker has been read: the single gC buffer may be rewritten
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) add_agent(&fl->c3, 1u);
-                    T2_DBG(bi - id.nct, 2, t2_x4(gsum)); T2_DBG(bi - id.nct, 3, t2_x4(kjp)); T2_DBG(bi - id.nct, 4, t2_x4(cj_prev));
-                    gsum = scale4(gsum, w * kSplitInv2);
-                    const float coefc = wave_sum(dot4(gsum, cj_prev));
-                    const float f = kap_prev * coefc, sc = rn_prev / fM;
-                    if (dact)
-                        *reinterpret_cast<float4*>(KJ + wid * D + d4) =
-                            make_float4((gsum.x - f * cj_prev.x) * sc + kjp.x, (gsum.y - f * cj_prev.y) * sc + kjp.y,
-                                        (gsum.z - f * cj_prev.z) * sc + kjp.z, (gsum.w - f * cj_prev.w) * sc + kjp.w);
-                }
-                __syncthreads();
-                // dE_r = held part + KJ_{speaker of r}: two or three speakers per 16-row block
-#pragma unroll
-                for (int i = 0; i < NTI; ++i) {
-                    const int dt = wid + 8 * i;
-#pragma unroll
-                    for (int rb = 0; rb < RBMAX; ++rb) {
-                        if (rb < RB) {
-                            const int r = 16 * rb + l15;
-                            const int loc = min((r * L.mul_m) >> 16, 7);
-                            const float4 kj = *reinterpret_cast<const float4*>(KJ + loc * D + min(16 * dt, D - 16) + 4 * q);
-                            const bool ok = r < R_my && dt < NT;
-                            const float4 h = held[i][rb];
-                            T2_DBG(bi - id.nct, 5 + rb, t2_x4(h));
-                            bstore4<AUX_NT>(rsGp, ok ? (unsigned)((j0 * M + r) * D + 16 * dt + 4 * q) * 4u : OOB,
-                                            make_float4(h.x + kj.x, h.y + kj.y, h.z + kj.z, h.w + kj.w));
-                        }
-                    }
-                }
-            }
-            GE2E_PROF(3);
+            __syncthreads();                 // also: every wave's ET rows and row scalars are written
+            if (*wsh == 0) { failed = true; break; }
         }
-        if (!have_cur) break;
+        GE2E_PROF(2);
 
-        GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under X .. GE
-
-        // ===== X(cur): X[r][slot] over this wave's K half -> LDS ====================================================
+        // ===== B: centroid fragments, previous batch's partial gradients and scalars -> registers ===================
+        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
+        h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
+        float4 part[TEAM];
+        float4 cstv = zero4(), scv = zero4();
         {
             GE2E_T2_LANE();
+            if (have_cur) {
+                const unsigned oa = L.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
+#pragma unroll
+                for (int s = 0; s < NCH; ++s) {
+                    xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
+                    xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
+                }
+                if (tid < NC) cstv = bload4<AUX_L2>(rsX, L.cst[buf] + (unsigned)tid * 16u, 0);
+            }
+            if (have_prev) {
+                if (id.member == 0 && tid < TEAM) scv = bload4<AUX_L2>(rsX, L.sc[pbuf] + (unsigned)tid * 16u, 0);
+            }
+        }
+
+        // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
+        if (have_cur) {
+            GE2E_T2_LANE();
             float* const XBk = khX ? XB1 : XB0;
+            const int off0 = l15 * P + 32 * khX * NCH + 8 * q;
+            h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
+            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
+#define T2_X_LOAD(T_)                                                                                     \
+    do {                                                                                                  \
+        fb[(T_) & 1][0] = frag_row(ETh + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+        fb[(T_) & 1][1] = frag_row(ETl + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+    } while (0)
+#define T2_X_STORE(RB_)                                                                       \
+    *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
+        make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
+            T2_X_LOAD(0);
 #pragma unroll
-            for (int rb = 0; rb < RBMAX; ++rb) {
-                if (rb < RB) {
-                    f32x4 acc = acc_zero4();
-                    const int off_b = (16 * rb + l15) * P + 32 * khX * NCH + 8 * q;
+            for (int rb = 0; rb < RBC; ++rb) {
+                if (CT_X || rb < RBr) {
+                    acc[rb & 1] = acc_zero4();
 #pragma unroll
-                    for (int s = 0; s < NCH; ++s)
-                        mfma16x3(acc, xa[s][0], xa[s][1], frag_row(ETh + off_b + 32 * s), frag_row(ETl + off_b + 32 * s));
-                    T2_SETTLE16(acc);
-                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]
-                    *reinterpret_cast<float4*>(XBk + (16 * rb + l15) * XP + 16 * tX + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    for (int s = 0; s < NCH; ++s) {
+                        const int t = rb * NCH + s;
+                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
+                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
+                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+                    }
+                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
+                    if (rb > 0) { T2_AFTER_1(acc[(rb & 1) ^ 1]); T2_X_STORE(rb - 1); }
                 }
             }
+            T2_SETTLE16_2(acc[0], acc[1]);
+            T2_KEEP(fb[0][0]); T2_KEEP(fb[0][1]); T2_KEEP(fb[1][0]); T2_KEEP(fb[1][1]);
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) { T2_KEEP(xa[s][0]); T2_KEEP(xa[s][1]); }
+            if (CT_X) { T2_X_STORE(RBT - 1); }
+            else {
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb)
+                    if (rb == RBr - 1) { T2_X_STORE(rb); }
+            }
+#undef T2_X_LOAD
+#undef T2_X_STORE
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
         }
+        // ---- previous batch: scalars out ----------------------------------------------------------------------------
+        if (have_prev) {
+            if (id.member == 0 && wid == 0) {
+                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+                if (lane == 0) {
+                    if (p.loss) p.loss[bi - id.nct] = l;
+                    if (p.dw) p.dw[bi - id.nct] = a;
+                    if (p.db) p.db[bi - id.nct] = c;
+                }
+            }
+        }
         __syncthreads();
-        GE2E_PROF(4);
+        GE2E_PROF(3);
 
         // ===== S(cur): leave-one-out statistics, S, loss, dL/dS -> G images, row coefficients =======================
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        {
+        if (have_cur) {
             GE2E_T2_LANE();
             const int c4 = 4 * l15;
             const int nval = max(0, min(spm, N - (l15 >> 1) * spm));   // valid slots of the member this lane's columns belong to
-            for (int pi = wid; 4 * pi < RT; pi += 8) {
-                const int r = 4 * pi + q;
-                const bool rv = r < R_my;
-                const int loc = min((r * L.mul_m) >> 16, 7);
-                const int ko = 8 * id.member + loc;                    // own-speaker slot of this row
-                const float4 x0 = *reinterpret_cast<const float4*>(XB0 + r * XP + c4);
-                const float4 x1 = *reinterpret_cast<const float4*>(XB1 + r * XP + c4);
-                const float xs[4] = {x0.x + x1.x, x0.y + x1.y, x0.z + x1.z, x0.w + x1.w};
-                const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
-                const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee
-                const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
-                const float rne = rv ? rs0.x : 0.f, ke = rs0.y, ee = rs0.z;
-                const float rne1 = rv ? rs0.x : 1.0f;
-                const float es = xo * cs.z / rne1;               // e . s_j
-                const float eu = (es - ee) * inv_m1;
-                const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
-                float rnu, ku;
-                unit_stats_fast(uu, eps_cos, rnu, ku);
-                const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
-                const float sjj = w * (cosd + eps) + bias;
-                float c0[4], sv[4], g[4];
+            const int kl = 4 * (l15 & 1);                              // slot index of column 0 inside its member
+            const bool kv0 = kl < nval, kv1 = kl + 1 < nval, kv2 = kl + 2 < nval, kv3 = kl + 3 < nval;
+            const int npass = CT_S ? RT / 4 : RBr * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = c4 + e;
-                    c0[e] = (k == ko) ? cosd : xs[e] * kSplitInv2;
-                    sv[e] = ((k & 7) < nval) ? w * (c0[e] + eps) + bias : -INFINITY;
-                }
-                float per;
-                if (!contrast) {
-                    float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-                    mx = fmaxf(row16_max(mx), log_eps);
-                    float zoff = 0.f;
+            for (int k = 0; k < (RBC * 4 + 7) / 8; ++k) {
+                const int pi = wid + 8 * k;
+                if (pi < npass) {
+                    const int r = 4 * pi + q;
+                    const bool rv = r < R_my;
+                    const int loc = min((r * L.mul_m) >> 16, 7);
+                    const int ko = 8 * id.member + loc;                    // own-speaker slot of this row
+                    const int dk = ko - c4;                                // own column = entry dk of this lane (if 0..3)
+                    const float4 x0 = *reinterpret_cast<const float4*>(XB0 + r * XP + c4);
+                    const float4 x1 = *reinterpret_cast<const float4*>(XB1 + r * XP + c4);
+                    const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
+                    const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee |e|
+                    const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
+                    const float rne = rs0.x, ke = rs0.y, ee = rs0.z, ne = rs0.w;        // all zero for rows without an embedding
+                    const float es = xo * cs.z * ne;                 // e . s_j
+                    const float eu = (es - ee) * inv_m1;
+                    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+                    float rnu, ku, nu;
+                    unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
+                    const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+                    const float sjj2 = fmaf(w2, cosd, b2);
+                    float c0[4], g[4];
+                    c0[0] = dk == 0 ? cosd : (x0.x + x1.x) * kSplitInv2;
+                    c0[1] = dk == 1 ? cosd : (x0.y + x1.y) * kSplitInv2;
+                    c0[2] = dk == 2 ? cosd : (x0.z + x1.z) * kSplitInv2;
+                    c0[3] = dk == 3 ? cosd : (x0.w + x1.w) * kSplitInv2;
+                    float per, ad0;
+                    if (!CONTRAST) {
+                        float sv[4];
+                        sv[0] = kv0 ? fmaf(w2, c0[0], b2) : -INFINITY;
+                        sv[1] = kv1 ? fmaf(w2, c0[1], b2) : -INFINITY;
+                        sv[2] = kv2 ? fmaf(w2, c0[2], b2) : -INFINITY;
+                        sv[3] = kv3 ? fmaf(w2, c0[3], b2) : -INFINITY;
+                        float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+                        mx = fmaxf(row16_max(mx), leps2);
+                        float zoff = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            g[e] = __builtin_amdgcn_exp2f(sv[e] - mx);   // 2^-inf = 0 for unused slots
+                            zoff += dk == e ? 0.f : g[e];
+                        }
+                        zoff = row16_sum(zoff) + __builtin_amdgcn_exp2f(leps2 - mx);
+                        const float z = zoff + __builtin_amdgcn_exp2f(sjj2 - mx);
+                        per = LN2 * ((mx - sjj2) + __builtin_amdgcn_logf(z));
+                        const float rz = rcp_nr(z);
+                        ad0 = rv ? -zoff * rz : 0.f;                 // dL/dS on the own-speaker column: -(1 - p_jj) = -z_off / z
+                        const float rzv = rv ? rz : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : g[e] * rzv;
+                    } else {
+                        float best = -INFINITY; int besti = 0x7fffffff;
+                        const bool kv[4] = {kv0, kv1, kv2, kv3};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sve = kv[e] ? fmaf(w2, c0[e], b2) : -INFINITY;
+                            if (dk != e && sve > best) { best = sve; besti = c4 + e; }
+                        }
+                        row16_argmax(best, besti);
+                        const float pos = rcp_nr(1.0f + __builtin_amdgcn_exp2f(-sjj2));
+                        const float neg = (N > 1) ? rcp_nr(1.0f + __builtin_amdgcn_exp2f(-best)) : 0.0f;
+                        per = 1.0f - pos + neg;
+                        ad0 = rv ? -pos * (1.0f - pos) : 0.f;
+                        const float gn = rv ? neg * (1.0f - neg) : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : ((c4 + e == besti && kv[e]) ? gn : 0.f);
+                    }
+                    float coef = 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        g[e] = __expf(sv[e] - mx);   // exp(-inf) = 0 for unused slots
-                        if (c4 + e != ko) zoff += g[e];
+                        dw_acc = fmaf(g[e], c0[e] + eps, dw_acc);
+                        db_acc += g[e];
+                        coef = fmaf(g[e], c0[e], coef);       // (dL/d e-hat) . e-hat / w, own-speaker term included
                     }
-                    zoff = row16_sum(zoff) + __expf(log_eps - mx);
-                    const float z = zoff + __expf(sjj - mx);
-                    per = (mx - sjj) + __logf(z);
-                    const float rz = 1.0f / z;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = (c4 + e == ko) ? -zoff * rz : g[e] * rz;   // 1 - p_jj = z_off / z
-                } else {
-                    float best = -INFINITY; int besti = 0x7fffffff;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = c4 + e;
-                        if (k != ko && sv[e] > best) { best = sv[e]; besti = k; }
+                    if (rv && l15 == 0) {
+                        loss_acc += per;
+                        if (p.per) p.per[(size_t)bi * NM + j0 * M + r] = per;
                     }
-                    row16_argmax(best, besti);
-                    const float pos = 1.0f / (1.0f + __expf(-sjj));
-                    const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
-                    per = 1.0f - pos + neg;
+                    if (want_grad) {
+                        coef = w * row16_sum(coef);
+                        // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
+                        // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
+                        // of s_j (o, in units of ra) without dividing by w
+                        const float ad = w * ad0;
+                        const float rho = rnu * inv_m1;
+                        const float t1 = ku * cosd * rho;                        // kappa_u cos rho
+                        const float c2_0 = rho * ad0 * (rne + t1);               // c2 / w
+                        const float c1 = -ke * coef * rne - ad * rho - w * c2_0 * ne;
+                        const float alpha = ad * rnu * (1.0f + t1 * ne);
+                        const float beta = -ad * rnu * t1;
+                        const float o = c2_0 * cs.z * ne;
+                        // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
+                        // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
+                        const float lam = cs.x * inv_m * w;
+                        if (l15 == 0)
+                            *reinterpret_cast<float4*>(RS + r * 8 + 4) =
+                                make_float4(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
+                                            c1 * kSplitInv,                                 // c1: of the e-hat image value (2^8)
+                                            (alpha * inv_m1 - lam * o) * kSplitInv,         // c3'
+                                            beta * inv_m1 * cs.z + lam * cs.y * o * xo);    // c4' (of c-hat_j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = c4 + e;
-                        g[e] = (k == ko) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
+                        for (int e = 0; e < 4; ++e) g[e] = (dk == e ? o : g[e]) * kSplitScale;
+                        put_split4(Gh, Gl, r * GP + c4, make_float4(g[0], g[1], g[2], g[3]));
                     }
                 }
-                float coef = 0.f, ad0 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = c4 + e;
-                    if (!rv || (k & 7) >= nval) g[e] = 0.f;
-                    dw_acc += g[e] * (c0[e] + eps);
-                    db_acc += g[e];
-                    coef += g[e] * c0[e];           // (dL/d e-hat) . e-hat / w, own-speaker term included
-                    if (k == ko) { ad0 = g[e]; g[e] = 0.f; }
-                }
-                coef = w * row16_sum(coef);
-                ad0 = row16_sum(ad0);               // dL/dS on the own-speaker column
-                if (rv && l15 == 0) {
-                    loss_acc += per;
-                    if (p.per) p.per[(size_t)bi * NM + j0 * M + r] = per;
-                }
-                if (want_grad) {
-                    // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
-                    // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
-                    // of s_j (o, in units of ra) without dividing by w
-                    const float ad = w * ad0;
-                    const float rho = rnu * inv_m1;
-                    const float c2_0 = rho * (ad0 * rne1 + ad0 * ku * cosd * rnu * inv_m1);
-                    const float c2 = w * c2_0;
-                    const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
-                    const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
-                    const float beta = -ad * rnu * ku * cosd * rho;
-                    const float o = rv ? c2_0 * cs.z / rne1 : 0.f;
-                    // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
-                    // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
-                    const float lam = cs.x / fM * w;
-                    if (l15 == 0)
-                        *reinterpret_cast<float4*>(RS + r * 8 + 4) =
-                            make_float4(rne * (w * kSplitInv2),                                   // ra: of the gE accumulator (2^16)
-                                        rv ? c1 * kSplitInv : 0.f,                                // c1: of the e-hat image value (2^8)
-                                        rv ? (alpha * inv_m1 - lam * o) * kSplitInv : 0.f,        // c3'
-                                        rv ? beta * inv_m1 * cs.z + lam * cs.y * o * xo : 0.f);   // c4' (of c-hat_j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c4 + e == ko) g[e] = o;
-                    put_split4(Gh, Gl, r * GP + c4, make_float4(g[0] * kSplitScale, g[1] * kSplitScale, g[2] * kSplitScale, g[3] * kSplitScale));
-                }
+                __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaved passes cost more registers than there are
             }
         }
         // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
@@ -612,19 +643,31 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
         db_acc = wave_sum(db_acc);
         if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
         __syncthreads();
-        GE2E_PROF(5);
-        if (tid == 0) {
+        GE2E_PROF(4);
+
+        // ===== F: member scalars out; KJ_j of prev (its partial gradients have arrived) and KJP'_j of cur ===========
+        // first the requests whose answers are needed a phase or more from now: GE's centroid fragments (k-group form)
+        // and the next batch's rows (in flight under GC / GE and the next A1)
+        {
+            GE2E_T2_LANE();
+            if (have_prev && want_grad && has_spk) {      // my speaker's eight partial gradients (they land under KJP below)
+                const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
+#pragma unroll
+                for (int m = 0; m < TEAM; ++m)
+                    part[m] = bload4<AUX_L2>(rsX, vrow + L.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
+            }
+        }
+        if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
             bstore4<GE2E_T2_ST_AUX>(rsX, L.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
-
-        if (want_grad) {
-            // ===== speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns) ==========
-            kjp = zero4();
-            if (has_spk) {
-                GE2E_T2_LANE();
+        if (want_grad && has_spk) {
+            GE2E_T2_LANE();
+            const float4 kjp_prev = kjp;
+            if (have_cur) {   // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
+                kjp = zero4();
                 const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
                 const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
 #pragma unroll
@@ -642,8 +685,71 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                 kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
                 if (!dact) kjp = zero4();
             }
-            GE2E_PROF(6);
+            if (have_prev) {
+                float4 gsum = part[0];
+#pragma unroll
+                for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+                // every partial of this speaker has been read (the sums above waited for them; nothing of this wave's
+                // is behind them that the counted wait would have to skip): the single gC buffer may be rewritten
+                asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
+                if (lane == 0) add_agent(&fl->c3, 1u);
+                gsum = scale4(gsum, w * kSplitInv2);
+                const float coefc = wave_sum(dot4(gsum, cj_prev));
+                const float f = kap_prev * coefc, sc = rn_prev * inv_m;
+                if (dact)
+                    *reinterpret_cast<float4*>(KJ + wid * D + d4) =
+                        make_float4((gsum.x - f * cj_prev.x) * sc + kjp_prev.x, (gsum.y - f * cj_prev.y) * sc + kjp_prev.y,
+                                    (gsum.z - f * cj_prev.z) * sc + kjp_prev.z, (gsum.w - f * cj_prev.w) * sc + kjp_prev.w);
+            }
+        }
+        if (want_grad) __syncthreads();
+        GE2E_PROF(5);
 
+        if (want_grad && have_prev) {
+            // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ============
+            // The sums are formed IN the held registers and stored from there: nothing writes those registers again
+            // before the next GE.  A store's data registers must not be reused soon after it: with the memory pipe backed
+            // up (ten 16-byte stores per lane here) a queued store reads its data late, and an LDS read returning into the
+            // same registers meanwhile is not held back -- whole 16 x 16 tiles of the LAST stores of this loop came out
+            // with the next tile's KJ values in 5-20 % of the launches when the sum lived in a reused temporary.
+            GE2E_T2_LANE();
+#pragma unroll
+            for (int i = 0; i < NTI; ++i) {
+                const int dt = wid + 8 * i;
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb) {
+                    if (CT_DE || rb < RBr) {
+                        const int r = 16 * rb + l15;
+                        const int loc = min((r * L.mul_m) >> 16, 7);
+                        const float4 kj = *reinterpret_cast<const float4*>(KJ + loc * D + min(16 * dt, D - 16) + 4 * q);
+                        const bool ok = r < R_my && dt < NT;
+                        held[i][rb].x += kj.x; held[i][rb].y += kj.y; held[i][rb].z += kj.z; held[i][rb].w += kj.w;
+                        bstore4<AUX_NT>(rsGp, ok ? (unsigned)((j0 * M + r) * D + 16 * dt + 4 * q) * 4u : OOB, held[i][rb]);
+
+                    }
+                }
+            }
+        }
+        GE2E_PROF(6);
+        if (!have_cur) break;
+
+        if (want_grad) {
+            {   // GE's centroid fragments (k-group form): requested here, they land under GC
+                GE2E_T2_LANE();
+                {
+#pragma unroll
+                    for (int i = 0; i < NTI; ++i) {
+                        const int dt = wid + 8 * i;
+                        const bool on = dt < NT;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const unsigned o = L.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
+                            ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
+                            ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
+                        }
+                    }
+                }
+            }
             // ===== GC: partial gC^T[d][k] = sum_r ET[r][d] G[r][k]; wave: slots 32 kh.., columns 64 sl.. ============
             {
                 GE2E_T2_LANE();
@@ -654,15 +760,34 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
-                    asm volatile("" : "+v"(gc[0]), "+v"(gc[1]));
-                    for (int s = 0; s < RB; ++s) {
-                        const h8 gh = frag_tr(Gh, GP, 16 * s, 32 * kh, lv_), gl = frag_tr(Gl, GP, 16 * s, 32 * kh, lv_);
+                    asm volatile("s_nop 4" : "+v"(gc[0]), "+v"(gc[1]));   // VALU write -> (asm) MFMA SrcC: see acc_zero4
+                    h8 gf[2][2], ef[2][2][2];     // [set][hi, lo], [set][b][hi, lo]
+#define T2_GC_LOAD(S_)                                                                   \
+    do {                                                                                 \
+        gf[(S_) & 1][0] = frag_tr(Gh, GP, 16 * (S_), 32 * kh, lv_);                     \
+        gf[(S_) & 1][1] = frag_tr(Gl, GP, 16 * (S_), 32 * kh, lv_);                     \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
+            ef[(S_) & 1][b][0] = frag_tr(ETh, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+            ef[(S_) & 1][b][1] = frag_tr(ETl, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+        }                                                                                \
+    } while (0)
+                    T2_GC_LOAD(0);
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            mfma32x3(gc[b], frag_tr(ETh, P, 16 * s, 64 * sl + 32 * b, lv_),
-                                     frag_tr(ETl, P, 16 * s, 64 * sl + 32 * b, lv_), gh, gl);
+                    for (int s = 0; s < RBC; ++s) {
+                        if (CT_GC || s < RBr) {
+                            if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) mfma32x3(gc[b], ef[s & 1][b][0], ef[s & 1][b][1], gf[s & 1][0], gf[s & 1][1]);
+                            __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+                        }
                     }
+#undef T2_GC_LOAD
                     T2_SETTLE32(gc[0], gc[1]);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        T2_KEEP(gf[st][0]); T2_KEEP(gf[st][1]);
+                        T2_KEEP(ef[st][0][0]); T2_KEEP(ef[st][0][1]); T2_KEEP(ef[st][1][0]); T2_KEEP(ef[st][1][1]);
+                    }
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -684,13 +809,20 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                 }
             }
             GE2E_PROF(7);
-
+        }
+        if (want_grad) {
             // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
             {
+#ifdef GE2E_T2_V9
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(127);
+#endif
                 GE2E_T2_LANE();
+                int rbg = RB;                      // run-time bound even when RB is a template constant: see the note below
+                asm volatile("" : "+s"(rbg));
 #pragma unroll
-                for (int rb = 0; rb < RBMAX; ++rb) {
-                    if (rb < RB) {
+                for (int rb = 0; rb < RBC; ++rb) {
+                    if (rb < rbg) {
                         const int r = 16 * rb + l15;
                         h8 gb[2][2];
 #pragma unroll
@@ -699,45 +831,79 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                             gb[s2][1] = frag_row(Gl + r * GP + 32 * s2 + 8 * q);
                         }
                         const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
+#ifdef GE2E_T2_V7
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  One tile at a time: chain, settle, epilogue
 #pragma unroll
                         for (int i = 0; i < NTI; ++i) {
-                            const int dt = wid + 8 * i;
-                            if (dt < NT) {
-                                f32x4 acc = acc_zero4();
-                                mfma16x3(acc, ga[i][0][0], ga[i][0][1], gb[0][0], gb[0][1]);
-                                mfma16x3(acc, ga[i][1][0], ga[i][1][1], gb[1][0], gb[1][1]);
-                                T2_SETTLE16(acc);
-                                // lane (r = l15, q) holds gE[r][16 dt + 4 q + i]
-                                const int eo = r * P + 16 * dt + 4 * q;
-                                const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo);
-                                held[i][rb] = make_float4(fmaf((float)eh[0], rc.y, fmaf((float)el[0], rc.y, acc[0] * rc.x)),
-                                                          fmaf((float)eh[1], rc.y, fmaf((float)el[1], rc.y, acc[1] * rc.x)),
-                                                          fmaf((float)eh[2], rc.y, fmaf((float)el[2], rc.y, acc[2] * rc.x)),
-                                                          fmaf((float)eh[3], rc.y, fmaf((float)el[3], rc.y, acc[3] * rc.x)));
+#ifdef GE2E_T2_V8
+                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) acc = mfma3_16(ga[i][s2][0], ga[i][s2][1], gb[s2][0], gb[s2][1], acc);
+#else
+                            f32x4 acc = acc_zero4();
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[s2][0], gb[s2][1]);
+                            T2_SETTLE16_1(acc);
+#endif
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                T2_KEEP(gb[s2][0]); T2_KEEP(gb[s2][1]); T2_KEEP(ga[i][s2][0]); T2_KEEP(ga[i][s2][1]);
                             }
+#ifdef GE2E_T2_V5
+                            T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc);
+                            T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc);
+#endif
+                            const int eo = r * P + min(16 * (wid + 8 * i), D - 16) + 4 * q;
+#ifdef GE2E_T2_V10
+                            int eo2 = eo;
+                            asm volatile("" : "+v"(eo2));
+                            const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo2);
+#else
+                            const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo);
+#endif
+                            held[i][rb] = make_float4(fmaf((float)eh[0], rc.y, fmaf((float)el[0], rc.y, acc[0] * rc.x)),
+                                                      fmaf((float)eh[1], rc.y, fmaf((float)el[1], rc.y, acc[1] * rc.x)),
+                                                      fmaf((float)eh[2], rc.y, fmaf((float)el[2], rc.y, acc[2] * rc.x)),
+                                                      fmaf((float)eh[3], rc.y, fmaf((float)el[3], rc.y, acc[3] * rc.x)));
                         }
+                        __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
                     }
                 }
             }
         }
+        // the next batch's rows.  Requested only now: 40 more live registers during GE would not fit (the kernel sits at
+        // 232 of 256), and a spill here is not just slow -- see the note on store data at the dE stores
+        GE2E_T2_LOAD_ROWS(bi + id.nct);
         // the next iteration's A rewrites the ET images and the stage inside the X block
         __syncthreads();
 #ifdef GE2E_T2_DEBUG
-        if (g_t2_dump && seq == 0) {   // everything GE read, dumped after the barrier (does not disturb GE itself)
-            unsigned* dst = g_t2_dump + ((size_t)bi * 8 + id.member) * 32768;   // 128 KB per (batch, member)
-            const unsigned* src = reinterpret_cast<const unsigned*>(smem_f);
-            const int n_et = RT * P;            // dwords of both ET images
-            for (int i = tid; i < n_et; i += 512) dst[i] = src[i];
-            const unsigned* gsrc = reinterpret_cast<const unsigned*>(Gh);
-            for (int i = tid; i < RT * GP; i += 512) dst[8192 + i] = gsrc[i];
-            const unsigned* rsrc_ = reinterpret_cast<const unsigned*>(RS);
-            for (int i = tid; i < RT * 8; i += 512) dst[12288 + i] = rsrc_[i];
-            for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h) {
-                const uint4 v = __builtin_bit_cast(uint4, ga[i][s2][h]);
-                unsigned* d = dst + 13312 + ((i * 4 + s2 * 2 + h) * 512 + tid) * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (want_grad) {
+#pragma unroll
+            for (int i = 0; i < NTI; ++i)
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb) T2_DBG(bi, i * 5 + rb, t2_x4(held[i][rb]));
+            if (g_t2_dump) {   // everything GE read, and what it produced, dumped after the barrier
+                unsigned* dst = g_t2_dump + ((size_t)bi * 8 + id.member) * 131072;   // 512 KB per (batch, member)
+                const unsigned* src = reinterpret_cast<const unsigned*>(smem_f);
+                for (int i = tid; i < RT * P; i += 512) dst[i] = src[i];                     // both ET images (dwords)
+                const unsigned* gsrc = reinterpret_cast<const unsigned*>(Gh);
+                for (int i = tid; i < RT * GP; i += 512) dst[22000 + i] = gsrc[i];
+                const unsigned* rsrc_ = reinterpret_cast<const unsigned*>(RS);
+                for (int i = tid; i < RT * 8; i += 512) dst[28000 + i] = rsrc_[i];
+                for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h) {
+                    const uint4 v = __builtin_bit_cast(uint4, ga[i][s2][h]);
+                    unsigned* d = dst + 30000 + ((i * 4 + s2 * 2 + h) * 512 + tid) * 4;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+                for (int i = 0; i < NTI; ++i) for (int rb = 0; rb < RBC; ++rb) {
+                    unsigned* d = dst + 50000 + ((i * 5 + rb) * 512 + tid) * 4;
+                    d[0] = __float_as_uint(held[i][rb].x); d[1] = __float_as_uint(held[i][rb].y);
+                    d[2] = __float_as_uint(held[i][rb].z); d[3] = __float_as_uint(held[i][rb].w);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
 #endif
         GE2E_PROF(8);
@@ -753,9 +919,9 @@ extern "C" void ge2e_debug_set_t2(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_d
 extern "C" void ge2e_debug_set_t2_dump(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_dump), &p, sizeof(p)); }
 #endif
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MR>
+template <int NCH, int MR, int RBT, bool CONTRAST>
 static hipError_t launch_nch(Problem& p, Team2Ws& L, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(ge2e_team2_kernel<NCH, MR>);
+    const void* fn = reinterpret_cast<const void*>(ge2e_team2_kernel<NCH, MR, RBT, CONTRAST>);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
@@ -769,8 +935,22 @@ static hipError_t launch_nch(Problem& p, Team2Ws& L, hipStream_t stream) {
     if (err != hipSuccess) return err;
     const int grid = team2_grid(p.B);
     if (nb < 1 || grid > nb * team2_cu_count()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((ge2e_team2_kernel<NCH, MR>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    hipLaunchKernelGGL((ge2e_team2_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
     return hipGetLastError();
+}
+template <int NCH, int MR>
+static hipError_t launch_variant(Problem& p, Team2Ws& L, hipStream_t stream) {
+#ifndef GE2E_T2_DEV0
+    if (NCH == 4 && MR == 10 && L.rt == 80)   // the metric shape: compile-time trip counts
+        return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
+#else
+    if (NCH == 4 && MR == 10) return launch_nch<4, 10, 0, false>(p, L, stream);
+#endif
+#ifdef GE2E_T2_DEV
+    return hipErrorInvalidValue;
+#else
+    return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
+#endif
 }
 
 hipError_t launch_team2(const Problem& p_in, hipStream_t stream) {
@@ -779,17 +959,17 @@ hipError_t launch_team2(const Problem& p_in, hipStream_t stream) {
     hipError_t err;
     if (p.M <= 10) {
         switch (p.D / 64) {
-            case 1: err = launch_nch<1, 10>(p, L, stream); break;
-            case 2: err = launch_nch<2, 10>(p, L, stream); break;
-            case 3: err = launch_nch<3, 10>(p, L, stream); break;
-            default: err = launch_nch<4, 10>(p, L, stream); break;
+            case 1: err = launch_variant<1, 10>(p, L, stream); break;
+            case 2: err = launch_variant<2, 10>(p, L, stream); break;
+            case 3: err = launch_variant<3, 10>(p, L, stream); break;
+            default: err = launch_variant<4, 10>(p, L, stream); break;
         }
     } else {
         switch (p.D / 64) {
-            case 1: err = launch_nch<1, 16>(p, L, stream); break;
-            case 2: err = launch_nch<2, 16>(p, L, stream); break;
-            case 3: err = launch_nch<3, 16>(p, L, stream); break;
-            default: err = launch_nch<4, 16>(p, L, stream); break;
+            case 1: err = launch_variant<1, 16>(p, L, stream); break;
+            case 2: err = launch_variant<2, 16>(p, L, stream); break;
+            case 3: err = launch_variant<3, 16>(p, L, stream); break;
+            default: err = launch_variant<4, 16>(p, L, stream); break;
         }
     }
     if (err != hipSuccess) return err;

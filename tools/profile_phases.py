@@ -28,6 +28,9 @@ PHASES = {
              "P2 centroid images -> LDS", "P3 X = CH.ET^T (+ dE stores of prev)", "P4 softmax in registers",
              "P5 KJP, gE tiles, scalars + barrier", "P6 G images", "P7 partial gC, rows request, publish, barrier",
              "wait 2 (partial gradients of prev)", "P8(prev) reduce -> KJ, dE complete"],
+    "team2": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
+              "B requests, X, partials requested + barrier", "S softmax, G images + barrier",
+              "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "GE + end barrier"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -40,9 +43,7 @@ def main():
     ap.add_argument("--batches", type=int, default=1024)
     args = ap.parse_args()
     lib_path = os.path.join(build.PKG_DIR, "libge2e_hip_prof.so")
-    cmd = [build._hipcc(), "-O3", "-std=c++17", f"--offload-arch={build.ARCH}", "-fPIC", "-shared",
-           "-DGE2E_PROFILE", f"-I{build.INCLUDE}", "-o", lib_path] + build.sources()
-    subprocess.run(cmd, check=True)
+    build.build_variant(lib_path, ["-DGE2E_PROFILE"] + os.environ.get("GE2E_EXTRA_DEFS", "").split())
     lib = C.CDLL(lib_path)
     for name, (res, argt) in _lib.PROTOTYPES.items():
         getattr(lib, name).restype = res
@@ -80,7 +81,7 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     cyc = prof.cpu().numpy().astype(float) / B
-    if args.impl == "team":
+    if args.impl in ("team", "team2"):
         cyc /= 8.0          # eight workgroups stamp every batch; report one workgroup's timeline
     tot = cyc.sum()
     names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])

@@ -3,7 +3,7 @@
 # usage: bash tools/run_sq_counters.sh   (writes gpurun_out/sq_<impl>_<set>/ and prints a digest)
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
-for impl in auto team; do
+for impl in ${IMPLS:-auto team}; do
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" \
              "SQ_INSTS_VMEM SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_INSTS_SMEM" \
@@ -17,7 +17,7 @@ done
 python3 - <<PY
 import csv, glob, os
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-for impl in ("auto", "team"):
+for impl in os.environ.get("IMPLS", "auto team").split():
     tot = {}
     for f in glob.glob(f"{root}/gpurun_out/sq_{impl}_*/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
