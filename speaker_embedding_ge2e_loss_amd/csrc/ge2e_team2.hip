@@ -30,19 +30,6 @@
 
 namespace ge2e {
 
-#ifdef GE2E_T2_DEBUG
-__device__ unsigned* g_t2_dbg = nullptr;   // [B][8 members][32 items][512 threads]
-__device__ unsigned* g_t2_dump = nullptr;  // [B][8 members][32768] dwords
-#define T2_DBG(batch, item, val)                                                                              \
-    do {                                                                                                      \
-        if (g_t2_dbg) g_t2_dbg[(((size_t)(batch) * 8 + id.member) * 32 + (item)) * 512 + threadIdx.x] = (val); \
-    } while (0)
-__device__ __forceinline__ unsigned t2_x4(const float4& v) {
-    return __float_as_uint(v.x) ^ (__float_as_uint(v.y) * 3u) ^ (__float_as_uint(v.z) * 5u) ^ (__float_as_uint(v.w) * 7u);
-}
-#else
-#define T2_DBG(batch, item, val)
-#endif
 
 
 namespace {
@@ -53,17 +40,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int NC = 64;        // centroid slots: member m owns 8 m .. 8 m + 7
 constexpr int GP = 72;        // G image pitch (halfs)
 constexpr int XP = 68;        // X block pitch (floats)
+constexpr int STGPAD = 32;    // centroid stage: rows 16 banks apart -> the transposing reads of a 4 x 32 block never collide
 constexpr int RTMAX = 80;     // rows of a member's images
 constexpr int RBMAX = RTMAX / 16;
 constexpr unsigned OOB = 0x7FFFFF00u;
 constexpr int AUX_L2 = 16;    // sc1: served by L2, never by this CU's L1 (hand-off reads)
 constexpr int AUX_NT = 2;
-#ifndef GE2E_T2_ST_AUX
-#define GE2E_T2_ST_AUX 0      // cache policy of the exchange stores (experiments: 16 = sc1, write-through)
-#endif
-#ifndef GE2E_T2_RELEASE
-#define GE2E_T2_RELEASE 0     // experiments: agent-scope release fence before the hand-off signals
-#endif
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -192,19 +174,12 @@ Team2Ws team2_layout(int N, int M, int D) {
     L.spm = (N + TEAM - 1) / TEAM;
     L.rt = (L.spm * M + 15) / 16 * 16;
     L.mul_m = (65536 + M - 1) / M;
-    unsigned o = 0;
-    for (int b = 0; b < 2; ++b) { L.chr[b] = o; o += (unsigned)NC * 2 * D * 2; }
-    for (int b = 0; b < 2; ++b) { L.cht[b] = o; o += (unsigned)TEAM * 2 * D * 16; }
-    for (int b = 0; b < 2; ++b) { L.cst[b] = o; o += NC * 16; }
-    for (int b = 0; b < 2; ++b) { L.sc[b] = o; o += TEAM * 16; }
-    o = (unsigned)align_up(o, 256);
-    L.gc = o; o += (unsigned)TEAM * NC * D * 4;
-    L.stride = align_up(o, 4096);
-    L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(Team2Flags), 256);
+    L.head_bytes = (unsigned)align_up(sizeof(TeamCtl) + 64 * sizeof(Team2Flags), 256);
     const int P = D + 16;
     const size_t et = (size_t)2 * L.rt * P * 2;
     size_t xb = (size_t)L.rt * XP * 4;                 // X half-blocks; the first also holds the KJ rows [8][D] of phase F,
-    if (xb < (size_t)8 * D * 4) xb = (size_t)8 * D * 4;   // the second stages the transposed centroid [2][D][8] halfs
+    if (xb < (size_t)8 * D * 4) xb = (size_t)8 * D * 4;   // the second stages the centroid for its k-group form:
+    if (xb < (size_t)2 * 8 * (D + STGPAD) * 2) xb = (size_t)2 * 8 * (D + STGPAD) * 2;   // [hi, lo][8 slots][D + 32] halfs
     const size_t g = (size_t)2 * L.rt * GP * 2;        // G images
     L.xb_bytes = (unsigned)xb;
     L.g_bytes = (unsigned)g;
@@ -232,7 +207,7 @@ static size_t team2_fb_bytes(int B, int N, int M, int D) {
 }
 size_t team2_workspace_bytes(int B, int N, int M, int D) {
     const Team2Ws L = team2_layout(N, M, D);
-    return align_up(L.head_bytes + (size_t)(team2_grid(B) / TEAM) * L.stride, 256) + team2_fb_bytes(B, N, M, D);
+    return align_up(L.head_bytes + (size_t)(team2_grid(B) / TEAM) * team2_exchange(D).stride, 256) + team2_fb_bytes(B, N, M, D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,18 +221,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     constexpr unsigned ROWB = D * 4;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
     constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
+    constexpr Team2X XO = team2_exchange(D);
     constexpr int RBC = RBT ? RBT : RBMAX;
     const int RB = RBT ? RBT : L.rt / 16;
     const int RT = 16 * RB;
-#ifndef GE2E_T2_CTMASK
-#define GE2E_T2_CTMASK 31
-#endif
-    int RBr = RB;                         // the same number, opaque to the compiler
-    asm volatile("" : "+s"(RBr));
-#define CT_X (RBT && (GE2E_T2_CTMASK & 1))
-#define CT_S (RBT && (GE2E_T2_CTMASK & 2))
-#define CT_DE (RBT && (GE2E_T2_CTMASK & 4))
-#define CT_GC (RBT && (GE2E_T2_CTMASK & 8))
+    const int RBr = RB;
+    constexpr bool CT_X = RBT != 0, CT_S = RBT != 0, CT_DE = RBT != 0, CT_GC = RBT != 0;
     _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
     _Float16* const ETl = ETh + RT * P;
     float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
@@ -269,7 +238,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     float* const RED = CST + NC * 4;                               // [32]
     int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
     float* const KJ = XB0;                                         // F: KJ_j rows [8][D] (X has been consumed by then)
-    _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: transposed centroid stage [hi, lo][D][8]
+    _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: centroid stage [hi, lo][8 slots][D + STGPAD]
+    constexpr int SP = D + STGPAD;
 
     const int N = p.N, M = p.M, NM = N * M;
     const int tid = threadIdx.x;
@@ -284,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
     if (id.team < 0) return;
     Team2Flags* const fl = flags + id.team;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
-        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * L.stride, (unsigned)L.stride);
+        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * XO.stride, XO.stride);
 
     const int spm = L.spm;
     const int j0 = id.member * spm;                    // first speaker of this member
@@ -374,34 +344,32 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
             split4(scale4(cj_cur, kSplitScale), hi, lo);
             {   // row-major image row of slot kslot: D hi halfs, then D lo halfs
                 const unsigned vh = dact ? (unsigned)d4 * 2u : OOB;
-                const unsigned o = L.chr[buf] + (unsigned)kslot * ROWB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + o, 0, GE2E_T2_ST_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + o + 2u * D, 0, GE2E_T2_ST_AUX);
+                const unsigned o = XO.chr[buf] + (unsigned)kslot * ROWB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + o + 2u * D, 0, 0);
             }
-            if (dact) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    STG[(d4 + e) * 8 + wid] = hi[e];
-                    STG[(D + d4 + e) * 8 + wid] = lo[e];
-                }
+            if (dact) {   // one 8-byte write per image: a row of the stage per wave
+                *reinterpret_cast<h4*>(STG + wid * SP + d4) = hi;
+                *reinterpret_cast<h4*>(STG + (8 + wid) * SP + d4) = lo;
             }
             // 1/max(|c|,eps), kappa, |s_j| (s_j = c-hat_j * that), |s_j|^2
-            bstore4<GE2E_T2_ST_AUX>(rsX, lane == 0 ? L.cst[buf] + (unsigned)kslot * 16u : OOB,
+            bstore4(rsX, lane == 0 ? XO.cst[buf] + (unsigned)kslot * 16u : OOB,
                                     make_float4(rn, kap, has_spk ? fM * nc : 0.f, has_spk ? ss : 0.f));
         }
         __syncthreads();
-        if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d)
-            const float4 v = *reinterpret_cast<const float4*>(STG + tid * 8);
-            bstore4<GE2E_T2_ST_AUX>(rsX, L.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, v);
+        if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d), gathered
+            // by the transposing LDS read (4 slots x 16 columns per 16 lanes, twice); whole waves only (2 D % 64 == 0)
+            const int hl = tid >= D, d = tid - hl * D;
+            const int l16 = tid & 15;
+            const _Float16* p0 = STG + (8 * hl + (l16 >> 2)) * SP + (d - l16) + 4 * (l16 & 3);
+            const h4 a = tr_read4(p0), b2 = tr_read4(p0 + 4 * SP);
+            const h8 v = __builtin_shufflevector(a, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            bstore4(rsX, XO.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, __builtin_bit_cast(float4, v));
         }
         // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-#if GE2E_T2_RELEASE
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             if (have_prev) add_agent(&fl->c2, 1u);
             if (have_cur) add_agent(&fl->c1, 1u);
         }
@@ -448,16 +416,16 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
         {
             GE2E_T2_LANE();
             if (have_cur) {
-                const unsigned oa = L.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
+                const unsigned oa = XO.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
 #pragma unroll
                 for (int s = 0; s < NCH; ++s) {
                     xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
                     xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
                 }
-                if (tid < NC) cstv = bload4<AUX_L2>(rsX, L.cst[buf] + (unsigned)tid * 16u, 0);
+                if (tid < NC) cstv = bload4<AUX_L2>(rsX, XO.cst[buf] + (unsigned)tid * 16u, 0);
             }
             if (have_prev) {
-                if (id.member == 0 && tid < TEAM) scv = bload4<AUX_L2>(rsX, L.sc[pbuf] + (unsigned)tid * 16u, 0);
+                if (id.member == 0 && tid < TEAM) scv = bload4<AUX_L2>(rsX, XO.sc[pbuf] + (unsigned)tid * 16u, 0);
             }
         }
 
@@ -654,14 +622,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                 const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
 #pragma unroll
                 for (int m = 0; m < TEAM; ++m)
-                    part[m] = bload4<AUX_L2>(rsX, vrow + L.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
+                    part[m] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
             }
         }
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
-            bstore4<GE2E_T2_ST_AUX>(rsX, L.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
+            bstore4(rsX, XO.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
         if (want_grad && has_spk) {
             GE2E_T2_LANE();
@@ -743,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                         const bool on = dt < NT;
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) {
-                            const unsigned o = L.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
+                            const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
                             ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
                             ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
                         }
@@ -798,114 +766,74 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
                     if (ok) {
                         // lane (k = l31, h): registers 4 g .. 4 g + 3 = columns 32 b + 8 g + 4 h + 0..3 of slot 32 kh + l31
                         const int l31 = lv_ & 31, h = lv_ >> 5;
-                        const unsigned ob = L.gc + (unsigned)((id.member * NC + 32 * kh + l31) * D + 64 * sl + 4 * h) * 4u;
+                        const unsigned ob = XO.gc + (unsigned)((id.member * NC + 32 * kh + l31) * D + 64 * sl + 4 * h) * 4u;
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
 #pragma unroll
                             for (int g4 = 0; g4 < 4; ++g4)
-                                bstore4<GE2E_T2_ST_AUX>(rsX, ob + (unsigned)(32 * b + 8 * g4) * 4u,
+                                bstore4(rsX, ob + (unsigned)(32 * b + 8 * g4) * 4u,
                                         make_float4(gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]));
                     }
                 }
             }
             GE2E_PROF(7);
         }
+        GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under GE and the next A1
         if (want_grad) {
             // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
+            // The G fragments of the next row block and this block's epilogue operands are requested before the MFMAs.
             {
-#ifdef GE2E_T2_V9
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(127);
-#endif
                 GE2E_T2_LANE();
-                int rbg = RB;                      // run-time bound even when RB is a template constant: see the note below
+                int rbg = RB;
                 asm volatile("" : "+s"(rbg));
+                h8 gb[2][2][2];             // [set][s2][hi, lo]: G rows 16 rb + l15, slots 32 s2 + 8 q ..
+#define T2_GE_LOAD(RB_)                                                                                      \
+    do {                                                                                                     \
+        const int r_ = 16 * (RB_) + l15;                                                                     \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
+            gb[(RB_) & 1][s2][0] = frag_row(Gh + r_ * GP + 32 * s2 + 8 * q);                                 \
+            gb[(RB_) & 1][s2][1] = frag_row(Gl + r_ * GP + 32 * s2 + 8 * q);                                 \
+        }                                                                                                    \
+    } while (0)
+                T2_GE_LOAD(0);
 #pragma unroll
                 for (int rb = 0; rb < RBC; ++rb) {
                     if (rb < rbg) {
                         const int r = 16 * rb + l15;
-                        h8 gb[2][2];
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            gb[s2][0] = frag_row(Gh + r * GP + 32 * s2 + 8 * q);
-                            gb[s2][1] = frag_row(Gl + r * GP + 32 * s2 + 8 * q);
-                        }
+                        if (rb > 0) T2_GE_LOAD(rb);
                         const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
-#ifdef GE2E_T2_V7
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
+                        h4 eh[NTI], el[NTI];
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            const int eo = r * P + min(16 * (wid + 8 * i), D - 16) + 4 * q;
+                            eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
+                            el[i] = *reinterpret_cast<const h4*>(ETl + eo);
+                        }
                         // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  One tile at a time: chain, settle, epilogue
 #pragma unroll
                         for (int i = 0; i < NTI; ++i) {
-#ifdef GE2E_T2_V8
-                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) acc = mfma3_16(ga[i][s2][0], ga[i][s2][1], gb[s2][0], gb[s2][1], acc);
-#else
                             f32x4 acc = acc_zero4();
 #pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[s2][0], gb[s2][1]);
+                            for (int s2 = 0; s2 < 2; ++s2)
+                                mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
                             T2_SETTLE16_1(acc);
-#endif
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
-                                T2_KEEP(gb[s2][0]); T2_KEEP(gb[s2][1]); T2_KEEP(ga[i][s2][0]); T2_KEEP(ga[i][s2][1]);
+                                T2_KEEP(gb[rb & 1][s2][0]); T2_KEEP(gb[rb & 1][s2][1]); T2_KEEP(ga[i][s2][0]); T2_KEEP(ga[i][s2][1]);
                             }
-#ifdef GE2E_T2_V5
-                            T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc);
-                            T2_SETTLE16_1(acc); T2_SETTLE16_1(acc); T2_SETTLE16_1(acc);
-#endif
-                            const int eo = r * P + min(16 * (wid + 8 * i), D - 16) + 4 * q;
-#ifdef GE2E_T2_V10
-                            int eo2 = eo;
-                            asm volatile("" : "+v"(eo2));
-                            const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo2);
-#else
-                            const h4 eh = *reinterpret_cast<const h4*>(ETh + eo), el = *reinterpret_cast<const h4*>(ETl + eo);
-#endif
-                            held[i][rb] = make_float4(fmaf((float)eh[0], rc.y, fmaf((float)el[0], rc.y, acc[0] * rc.x)),
-                                                      fmaf((float)eh[1], rc.y, fmaf((float)el[1], rc.y, acc[1] * rc.x)),
-                                                      fmaf((float)eh[2], rc.y, fmaf((float)el[2], rc.y, acc[2] * rc.x)),
-                                                      fmaf((float)eh[3], rc.y, fmaf((float)el[3], rc.y, acc[3] * rc.x)));
+                            held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
+                                                      fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
+                                                      fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
+                                                      fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
                         }
                         __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
                     }
                 }
+#undef T2_GE_LOAD
             }
         }
-        // the next batch's rows.  Requested only now: 40 more live registers during GE would not fit (the kernel sits at
-        // 232 of 256), and a spill here is not just slow -- see the note on store data at the dE stores
-        GE2E_T2_LOAD_ROWS(bi + id.nct);
         // the next iteration's A rewrites the ET images and the stage inside the X block
         __syncthreads();
-#ifdef GE2E_T2_DEBUG
-        if (want_grad) {
-#pragma unroll
-            for (int i = 0; i < NTI; ++i)
-#pragma unroll
-                for (int rb = 0; rb < RBC; ++rb) T2_DBG(bi, i * 5 + rb, t2_x4(held[i][rb]));
-            if (g_t2_dump) {   // everything GE read, and what it produced, dumped after the barrier
-                unsigned* dst = g_t2_dump + ((size_t)bi * 8 + id.member) * 131072;   // 512 KB per (batch, member)
-                const unsigned* src = reinterpret_cast<const unsigned*>(smem_f);
-                for (int i = tid; i < RT * P; i += 512) dst[i] = src[i];                     // both ET images (dwords)
-                const unsigned* gsrc = reinterpret_cast<const unsigned*>(Gh);
-                for (int i = tid; i < RT * GP; i += 512) dst[22000 + i] = gsrc[i];
-                const unsigned* rsrc_ = reinterpret_cast<const unsigned*>(RS);
-                for (int i = tid; i < RT * 8; i += 512) dst[28000 + i] = rsrc_[i];
-                for (int i = 0; i < NTI; ++i) for (int s2 = 0; s2 < 2; ++s2) for (int h = 0; h < 2; ++h) {
-                    const uint4 v = __builtin_bit_cast(uint4, ga[i][s2][h]);
-                    unsigned* d = dst + 30000 + ((i * 4 + s2 * 2 + h) * 512 + tid) * 4;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
-                for (int i = 0; i < NTI; ++i) for (int rb = 0; rb < RBC; ++rb) {
-                    unsigned* d = dst + 50000 + ((i * 5 + rb) * 512 + tid) * 4;
-                    d[0] = __float_as_uint(held[i][rb].x); d[1] = __float_as_uint(held[i][rb].y);
-                    d[2] = __float_as_uint(held[i][rb].z); d[3] = __float_as_uint(held[i][rb].w);
-                }
-                __syncthreads();
-            }
-        }
-#endif
         GE2E_PROF(8);
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -914,10 +842,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team2_kernel(Problem p, Team2Ws L
 #undef GE2E_T2_LANE
 }
 
-#ifdef GE2E_T2_DEBUG
-extern "C" void ge2e_debug_set_t2(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_dbg), &p, sizeof(p)); }
-extern "C" void ge2e_debug_set_t2_dump(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_t2_dump), &p, sizeof(p)); }
-#endif
 // ---------------------------------------------------------------------------------------------
 template <int NCH, int MR, int RBT, bool CONTRAST>
 static hipError_t launch_nch(Problem& p, Team2Ws& L, hipStream_t stream) {
@@ -940,17 +864,9 @@ static hipError_t launch_nch(Problem& p, Team2Ws& L, hipStream_t stream) {
 }
 template <int NCH, int MR>
 static hipError_t launch_variant(Problem& p, Team2Ws& L, hipStream_t stream) {
-#ifndef GE2E_T2_DEV0
     if (NCH == 4 && MR == 10 && L.rt == 80)   // the metric shape: compile-time trip counts
         return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
-#else
-    if (NCH == 4 && MR == 10) return launch_nch<4, 10, 0, false>(p, L, stream);
-#endif
-#ifdef GE2E_T2_DEV
-    return hipErrorInvalidValue;
-#else
     return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
-#endif
 }
 
 hipError_t launch_team2(const Problem& p_in, hipStream_t stream) {
@@ -979,7 +895,7 @@ hipError_t launch_team2(const Problem& p_in, hipStream_t stream) {
     f.gate = &ctl->abort_;
     f.grid_cap = TEAM2_FALLBACK_GRID;
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
-                                    align_up(L.head_bytes + (size_t)(team2_grid(p.B) / TEAM) * L.stride, 256));
+                                    align_up(L.head_bytes + (size_t)(team2_grid(p.B) / TEAM) * team2_exchange(p.D).stride, 256));
     return launch_fused_split(f, stream);
 }
 

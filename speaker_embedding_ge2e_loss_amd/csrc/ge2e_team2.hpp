@@ -13,21 +13,36 @@ struct Team2Flags {
     unsigned c3;   unsigned pad2[31];   // partial gradients of a batch have been READ       (+1 per speaker)
 };
 
-struct Team2Ws {
-    int spm;            // speaker slots per member = ceil(N / 8) (<= 8)
-    int rt;             // rows of a member's images: spm * M rounded up to 16 (<= 80)
-    int mul_m;          // ceil(2^16 / M): r / M = (r * mul_m) >> 16 for r < 2^16 / M
-    // per-team exchange area, byte offsets from the team's base
+// Per-team exchange area (byte offsets from the team's base): a function of D alone, so the kernel (templated on D)
+// folds every offset into an immediate instead of keeping a dozen SGPRs live.
+struct Team2X {
     unsigned chr[2];    // [64 slots][hi D | lo D] halfs      unit centroids * 2^8, row-major          (double-buffered)
     unsigned cht[2];    // [8 members][hi, lo][D][8 slots]    the same, one 16-byte k-group per d       (double-buffered)
     unsigned cst[2];    // [64][4] floats                     1/|c|, kappa, |s|, |s|^2                  (double-buffered)
     unsigned sc[2];     // [8][4] floats                      loss, dw, db partials                     (double-buffered)
     unsigned gc;        // [8 members][64 slots][D] floats    partial centroid gradients (single buffer, guarded by c3)
-    size_t stride;      // bytes per team
-    size_t head_bytes;  // TeamCtl + Team2Flags[64]
-    size_t fb_off;      // workspace of the gated fall-back launch (bytes from the workspace base)
-    size_t lds_bytes;
+    unsigned stride;    // bytes per team
+};
+constexpr Team2X team2_exchange(int D) {
+    Team2X x{};
+    unsigned o = 0;
+    for (int b = 0; b < 2; ++b) { x.chr[b] = o; o += 64u * 2 * D * 2; }
+    for (int b = 0; b < 2; ++b) { x.cht[b] = o; o += 8u * 2 * D * 16; }
+    for (int b = 0; b < 2; ++b) { x.cst[b] = o; o += 64 * 16; }
+    for (int b = 0; b < 2; ++b) { x.sc[b] = o; o += 8 * 16; }
+    o = (o + 255u) / 256u * 256u;
+    x.gc = o; o += 8u * 64 * D * 4;
+    x.stride = (o + 4095u) / 4096u * 4096u;
+    return x;
+}
+
+struct Team2Ws {
+    int spm;            // speaker slots per member = ceil(N / 8) (<= 8)
+    int rt;             // rows of a member's images: spm * M rounded up to 16 (<= 80)
+    int mul_m;          // ceil(2^16 / M): r / M = (r * mul_m) >> 16 for r < 2^16 / M
+    unsigned head_bytes;   // TeamCtl + Team2Flags[64]
     unsigned xb_bytes, g_bytes;   // LDS regions that are shared by two uses (see the kernel)
+    size_t lds_bytes;
 };
 
 constexpr int TEAM2_FALLBACK_GRID = 32;   // workgroups of the gated fall-back launch
