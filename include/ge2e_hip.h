@@ -47,10 +47,9 @@ extern "C" {
 #define GE2E_IMPL_FUSED_SPLIT 3 /* as FUSED_F32 with fp16 hi+lo split operands on
                                    v_mfma_f32_32x32x16_f16, fp32 accumulate      */
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
-#define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, E resident in LDS: E read once */
-#define GE2E_IMPL_TEAM2 6       /* as TEAM on flat 16-row blocks, centroid operands in registers, one
-                                   exchange buffer per team; falls back to FUSED_SPLIT inside the same
-                                   call if the teams cannot form                                        */
+#define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, the member's rows resident in LDS: E is
+                                   read once.  Falls back to FUSED_SPLIT inside the same call (a gated second
+                                   launch) if the teams cannot form or a hand-off times out                   */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */
@@ -126,6 +125,12 @@ int ge2e_selftest_rows16(const float* CH, const float* R, float* XT, float* GE, 
 size_t ge2e_selftest_team_bytes(int payload_f4);
 int ge2e_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds, int payload_f4, unsigned* out,
                        void* stream);
+
+/* ge2e_loss_fwd_bwd with impl = GE2E_IMPL_TEAM and the team kernel's abort word raised before the launch: exercises the
+ * in-call fall-back (the gated one-workgroup-per-batch launch) deterministically.  Same arguments and results. */
+int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, const float* w, const float* b,
+                                float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
+                                float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

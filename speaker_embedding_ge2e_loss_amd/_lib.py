@@ -14,9 +14,9 @@ ABI_VERSION = 1
 
 VARIANT_SOFTMAX, VARIANT_CONTRAST = 0, 1
 VARIANTS = {"softmax": VARIANT_SOFTMAX, "contrast": VARIANT_CONTRAST}
-IMPL_AUTO, IMPL_GENERIC, IMPL_FUSED_F32, IMPL_FUSED_SPLIT, IMPL_TILED, IMPL_TEAM, IMPL_TEAM2 = 0, 1, 2, 3, 4, 5, 6
+IMPL_AUTO, IMPL_GENERIC, IMPL_FUSED_F32, IMPL_FUSED_SPLIT, IMPL_TILED, IMPL_TEAM = 0, 1, 2, 3, 4, 5
 IMPLS = {"auto": IMPL_AUTO, "generic": IMPL_GENERIC, "fused_f32": IMPL_FUSED_F32,
-         "fused_split": IMPL_FUSED_SPLIT, "tiled": IMPL_TILED, "team": IMPL_TEAM, "team2": IMPL_TEAM2}
+         "fused_split": IMPL_FUSED_SPLIT, "tiled": IMPL_TILED, "team": IMPL_TEAM}
 IMPL_NAMES = {v: k for k, v in IMPLS.items()}
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -40,6 +40,8 @@ PROTOTYPES = {
     "ge2e_selftest_team_bytes": (C.c_size_t, [C.c_int]),
     "ge2e_selftest_team": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_centroids": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ge2e_selftest_team_fallback": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
+                                              C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
 }
 
 _lib = None

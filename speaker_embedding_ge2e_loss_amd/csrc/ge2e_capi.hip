@@ -9,8 +9,7 @@
 #include "ge2e_fused.hpp"
 #include "ge2e_selftest.hpp"
 #include "ge2e_tiled.hpp"
-#include "ge2e_team.hpp"
-#include "ge2e_team2.hpp"
+#include "ge2e_team_kernel.hpp"
 
 using namespace ge2e;
 
@@ -22,16 +21,17 @@ unsigned long long* g_prof = nullptr;  // diagnostic build only
 
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
-// AUTO: few batches -> a team of eight CUs per batch (measured at N=64, M=10, D=256, back-to-back launches:
-// 38 us vs 128 us for B = 1, 76 us vs 136 us for B = 64, 126 us vs 146 us for B = 128, break-even at
-// B ~ 150); many batches -> one workgroup per batch.
-constexpr int kTeamMaxB = 144;
+// AUTO at shapes both accept (measured at N=64, M=10, D=256, interleaved in one process, tools/compare_impls.py):
+// the eight-CU team kernel wins up to B ~ 200 (27 us vs 118 us at B = 1, 100 us vs 131 us at B = 128), the
+// one-workgroup-per-batch kernel wins in between (B = 256: 162 us vs 178 us), and from B ~ 2000 the two tie in time
+// (B = 4096: 2.39 ms both) while the team kernel moves 1.65x instead of 2.5x the algorithmic bytes: it takes those too.
+constexpr int kTeamMaxB = 192, kTeamMinLargeB = 2048;
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
-            if (B <= kTeamMaxB && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
+            if ((B <= kTeamMaxB || B >= kTeamMinLargeB) && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;
@@ -39,7 +39,6 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_ERR_IMPL;
         case GE2E_IMPL_TILED: return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_ERR_IMPL;
         case GE2E_IMPL_TEAM: return team_supports(N, M, D) ? GE2E_IMPL_TEAM : GE2E_ERR_IMPL;
-        case GE2E_IMPL_TEAM2: return team2_supports(N, M, D) ? GE2E_IMPL_TEAM2 : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -51,7 +50,6 @@ size_t ws_bytes(int B, int N, int M, int D, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TILED: return tiled_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TEAM: return team_workspace_bytes(B, N, M, D);
-        case GE2E_IMPL_TEAM2: return team2_workspace_bytes(B, N, M, D);
         default: return 0;
     }
 }
@@ -76,7 +74,6 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
         case GE2E_IMPL_FUSED_SPLIT: err = launch_fused_split(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TILED: err = launch_tiled(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TEAM: err = launch_team(p, (hipStream_t)stream); break;
-        case GE2E_IMPL_TEAM2: err = launch_team2(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;
@@ -160,6 +157,20 @@ int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void
     if (!E || !cent) return GE2E_ERR_NULL;
     if (B < 1 || N < 1 || M < 1 || D < 1) return GE2E_ERR_SHAPE;
     return (int)launch_centroids(E, B, N, M, D, cent, (hipStream_t)stream);
+}
+
+// GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the gated fall-back launch does the work.
+int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, const float* w, const float* b,
+                                float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
+                                float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!E || !w || !b || !loss) return GE2E_ERR_NULL;
+    if (dE && (!dw || !db)) return GE2E_ERR_NULL;
+    Problem p{};
+    p.E = E; p.w = w; p.b = b; p.loss = loss; p.per = per_emb_loss;
+    p.dE = dE; p.dw = dw; p.db = db; p.cos_out = nullptr;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = variant; p.eps_cos = eps_cos; p.eps = eps;
+    p.test_abort = 1;
+    return run(p, GE2E_IMPL_TEAM, workspace, workspace_bytes, stream);
 }
 
 int ge2e_selftest_split_gemm(const float* A, const float* Bm, const float* G, float* X, float* GE, float* GC,

@@ -27,8 +27,9 @@ struct Problem {
     float eps;        // hp.general.small_err (1e-6)
     float log_eps;    // logf(eps), -inf when eps == 0
     unsigned long long* prof;  // diagnostic builds (-DGE2E_PROFILE) only: per-phase cycle sums
-    const unsigned* gate;      // non-null: the launch is a fall-back that runs only if *gate != 0 (ge2e_team2.hip)
+    const unsigned* gate;      // non-null: the launch is a fall-back that runs only if *gate != 0 (ge2e_team.hip)
     int grid_cap;              // > 0: at most this many workgroups (the fall-back's workspace is sized for it)
+    int test_abort;            // diagnostics: the team launch starts with its abort word raised (exercises the fall-back)
 };
 
 // In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with

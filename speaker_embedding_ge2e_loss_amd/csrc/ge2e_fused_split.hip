@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const int sl = wid & 3;           //                        64-column slice of d
     const bool slice_on = 64 * sl < D;
 
-    // fall-back launch behind the team kernel (ge2e_team2.hip): nothing to do unless its abort word is up
+    // fall-back launch behind the team kernel (ge2e_team.hip): nothing to do unless its abort word is up
     if (p.gate && __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int spt = wsl.spt;          // speakers per tile
     const int ntiles = wsl.ntiles;

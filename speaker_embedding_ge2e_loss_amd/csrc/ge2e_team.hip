@@ -1,55 +1,56 @@
-// GE2E_IMPL_TEAM: eight workgroups on eight CUs of one XCD share a batch, E is read from HBM ONCE.
+// GE2E_IMPL_TEAM: eight workgroups on eight CUs of one XCD share a batch; E is read from HBM ONCE and every
+// phase works on flat 16-row blocks of the member's rows, so nothing is padded from M rows to an MFMA block.
 //
-// The one-workgroup-per-batch kernels (ge2e_fused_*.hip) stream E three times because a batch
-// (N M D fp32 = 655 KB at N=64, M=10, D=256) does not fit one CU.  Split over eight CUs it does:
-// member m of a team keeps the rows of its N/8 speakers resident in LDS (as fp16 hi / lo unit-row
-// images, 84 KB) next to all 64 unit centroids (68 KB), and the three dependent passes of the loss
-// become phases over resident data with two exchanges through the XCD's L2 in between
-// (ge2e_team.hpp: team formation and the hand-off protocol):
+// Member m of a team owns the speaker slots 8 m .. 8 m + spm - 1 (spm = ceil(N / 8)) and their R = spm M rows.
+// LDS holds only the member's OWN data: its rows as fp16 hi / lo unit-row images ET (87 KB at N=64, M=10, D=256),
+// the similarity block X (two K-halves, fp32) and the dL/dS images G.  The 64 unit centroids never enter LDS: each
+// wave keeps the MFMA fragments it needs in registers, loaded straight from the team's L2-resident exchange area
+// (row-major for X = ET . CH^T, and as 16-byte k-groups per column for gE = G . CH).
 //
-//   P1  wave s owns local speaker s: its M rows (requested a phase-group earlier) -> speaker sum -> unit
-//       centroid, published to the team as finished fp16 hi / lo image rows             [hand-off 1];
-//       per row |e|, e-hat -> ET images
-//   P2  all 64 published centroid rows -> CH images (a pure copy, identical bits on every member)
-//   P3  X[k][r] = CH . ET^T for the wave's own 16 (>= M) rows: 16 x 16 x 32 split-fp16 MFMA tiles;
-//       lane (r = lane & 15, q = lane >> 4) ends up with X[16 t + 4 q + i][r].  Each K-step also stores
-//       two finished 16-byte tiles of the PREVIOUS batch's dE (the only write of dE)
-//   P4  leave-one-out statistics, softmax / contrast, dL/dS -- in registers: a row's 64 columns sit
-//       in 16 registers of 4 lanes (l, l^16, l^32, l^48)
-//   P5  per-speaker row KJP_j = sum_i c3_i e-hat_i + (sum_i c4_i) s_j (all rows of j are in this wave;
-//       c3_i broadcast by v_readlane); gE = G . CH with G taken straight from the registers as the A
-//       operand (no LDS trip), three tiles in flight; ra gE + c1 e-hat stays in registers (64 VGPRs)
-//   P6  G (the same fp16 fragments) -> hi / lo images over the (now dead) centroid images
-//   P7  partial gC[k][d] = sum_{own rows} G[r][k] e-hat[r][d] (32 x 32 x 16 tiles, all 8 waves)
-//       -> published, with the member's loss / dw / db partials                          [hand-off 2]
-//   P8  wave s sums the eight partials of ITS speaker in member order, maps them through the
-//       centroid norm -> KJ_j; held rows += rc c-hat_j + KJ_j: dE complete, stored under the next P3.
-// The loop is rotated (P1 of batch n runs before P8 of batch n - 1, one drain + barrier signals both
-// hand-offs; see the comment at the loop) so that no wait is exposed.
+//   A    wave s = speaker slot s: its M rows (prefetched registers) -> |e|, e-hat -> ET images; speaker sum ->
+//        unit centroid -> published in both forms                                                   [hand-off 1]
+//   B    centroid fragments -> registers (64 VGPRs); beside it FINISH of the previous batch: the eight partial
+//        centroid gradients of my speaker -> KJ_j -> dE = held + KJ_j -> HBM (the only write of dE)
+//   X    wave (t, kh): X[all rows][slots 16 t ..] over the K half kh -> LDS (60 MFMAs a wave, SIMD-balanced)
+//   S    softmax / contrast on X, 16 lanes per row: leave-one-out statistics, loss, dL/dS -> G images,
+//        row coefficients
+//   GC   partial gC^T[d][k] = sum_r ET[r][d] G[r][k] (32 x 32 x 16 tiles) -> published                [hand-off 2]
+//   GE   gE[d][r] = sum_k CH[k][d] G[r][k] with the centroid fragments from registers; ra gE + c1 e-hat is held
+//        in registers (40 VGPRs) until the partial gradients of the other members arrive
+// The own-speaker column of a row carries the coefficient of s_j in the G image (so GE adds that term for free);
+// what that entry adds to the member's own partial gC is taken out again algebraically in KJ_j (see S).
 //
-// HBM traffic per batch: E read once, dE written once (+ the published rows: 64 KB centroids and
-// 8 x 64 KB partial gradients, which live in L2 and are written through once).
-// Everything a wave does between the two hand-offs concerns its own speaker: the own-speaker column,
-// the leave-one-out centroid, c-hat_j and KJ_j are wave-uniform.
+// Exchange per batch and team: 128 KB of centroids (double-buffered) + 512 KB of partial gradients in ONE buffer,
+// guarded by a read-done counter, so the four teams of an XCD keep 2.6 MB live in its 4 MiB L2.
 #include "ge2e_common.hpp"
 #include "ge2e_split_gemm.hpp"
 #include "ge2e_team.hpp"
+#include "ge2e_team_kernel.hpp"
+#include "ge2e_fused.hpp"
 
 namespace ge2e {
+
+
 
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NC = 64;       // centroid slots
-constexpr int GP = 72;       // G image pitch (halfs)
-constexpr int MAXM = 16;     // rows of one speaker = one 16-row MFMA block
+constexpr int NC = 64;        // centroid slots: member m owns 8 m .. 8 m + 7
+constexpr int GP = 72;        // G image pitch (halfs)
+constexpr int XP = 68;        // X block pitch (floats)
+constexpr int STGPAD = 32;    // centroid stage: rows 16 banks apart -> the transposing reads of a 4 x 32 block never collide
+constexpr int RTMAX = 80;     // rows of a member's images
+constexpr int RBMAX = RTMAX / 16;
 constexpr unsigned OOB = 0x7FFFFF00u;
-constexpr int AUX_L2 = 16;   // sc1: served by L2, never by this CU's L1 (hand-off reads)
+constexpr int AUX_L2 = 16;    // sc1: served by L2, never by this CU's L1 (hand-off reads)
 constexpr int AUX_NT = 2;
-#ifndef GE2E_TEAM_E_AUX
-#define GE2E_TEAM_E_AUX 0
+#ifndef GE2E_T2_DE_AUX
+#define GE2E_T2_DE_AUX 2      // cache policy of the dE stores (tools/bench_variants.py sweeps it)
+#endif
+#ifndef GE2E_T2_E_AUX
+#define GE2E_T2_E_AUX 2       // ... and of the E loads
 #endif
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -66,10 +67,14 @@ template <int AUX = 0>
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
 }
+template <int AUX = 0>
+__device__ __forceinline__ h8 bload_h8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
 // whole offset in the VGPR, immediate soffset (ge2e_fused_split.hip: the register-soffset store hazard)
 template <int AUX = 0>
-__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, AUX);
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, const float4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, AUX);
 }
 __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& rn, float& kappa) {
     if (sq > eps_cos * eps_cos && sq < 1e30f) {
@@ -81,256 +86,291 @@ __device__ __forceinline__ void unit_stats_fast(float sq, float eps_cos, float& 
         unit_stats(sq, eps_cos, rn, kappa);
     }
 }
+// x / max(|x|, eps) bookkeeping without a branch: rn = 1 / max(|x|, eps), kappa = clamped / true norm (0 for a
+// zero vector), nc = max(|x|, eps).  v_rsq_f32 + one Newton step instead of sqrt and two IEEE divisions.
+__device__ __forceinline__ void unit_stats_bf(float sq, float eps_cos, float eps_cos2, float& rn, float& kappa, float& nc) {
+    const float sqc = fmaxf(sq, eps_cos2);
+    float r = __builtin_amdgcn_rsqf(sqc);
+    r = r * (1.5f - 0.5f * sqc * r * r);
+    rn = r;
+    nc = sqc * r;
+    kappa = sq >= eps_cos2 ? 1.0f : (sq > 1e-36f ? eps_cos * __builtin_amdgcn_rsqf(sq) : 0.0f);
+}
+__device__ __forceinline__ float rcp_nr(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
 __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, int off, const float4& x) {
     h4 hi, lo;
     split4(x, hi, lo);
     *reinterpret_cast<h4*>(hi_img + off) = hi;
     *reinterpret_cast<h4*>(lo_img + off) = lo;
 }
-__device__ __forceinline__ float4 get_join4(const _Float16* hi_img, const _Float16* lo_img, int off) {
-    return join4(*reinterpret_cast<const h4*>(hi_img + off), *reinterpret_cast<const h4*>(lo_img + off));
+
+// MFMAs as inline asm with the accumulator TIED to the destination.  With the builtins hipcc is free to give a chain
+//   v[12:15] = A.B + 0 ;  v[8:11] = A.B' + v[12:15] ;  ds_read_b128 v[12:15], ...   (next fragment into the dead SrcC)
+// and on gfx950 the matrix pipe reads SrcC pass by pass: when the pipe is shared with the SIMD's other wave the MFMA
+// can start late, the LDS read lands first, and the rows of the LAST pass (accumulator lanes 48..63) pick up the new
+// fragment bits instead of the partial sum.  Found with per-thread checksums of two identical launches: every input of
+// GE identical, `held` different in lanes q = 3 only, in 5-75 % of the launches depending on how long the phase ran.
+// A tied accumulator is only ever written by the (in-order) matrix pipe.  Each accumulator's MFMAs are issued BACK TO
+// BACK: with a second, independent chain interleaved (distance 2 between dependent MFMAs) whole 16 x 16 tiles came out
+// wrong whenever the SIMD's other wave was not issuing MFMAs of the same kind at the same time (first / last row block
+// of GE); hipcc would have padded that case with wait states, asm gets none.  hipcc pads nothing around asm, so the wait
+// states between the last MFMA of a chain and the first read of its result are spelled out (T2_SETTLE*).
+__device__ __forceinline__ void mfma16(f32x4& acc, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-// reductions over the four lanes l, l^16, l^32, l^48 (one row of the X block), result in all four
-__device__ __forceinline__ float col4_sum(float v) {
-    auto a = GE2E_SWAP16(__float_as_uint(v));
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = GE2E_SWAP32(__float_as_uint(v));
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+__device__ __forceinline__ void mfma32(f32x16& acc, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ float col4_max(float v) {
-    auto a = GE2E_SWAP16(__float_as_uint(v));
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    auto b = GE2E_SWAP32(__float_as_uint(v));
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+// acc += (ah + al) . (bh + bl) without the lo.lo term
+__device__ __forceinline__ void mfma16x3(f32x4& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
+    mfma16(acc, ah, bh); mfma16(acc, ah, bl); mfma16(acc, al, bh);
 }
-__device__ __forceinline__ void col4_argmax(float& v, int& i) {
-    {
-        auto a = GE2E_SWAP16(__float_as_uint(v));
-        auto b = GE2E_SWAP16((unsigned)i);
-        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
-        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
-        v = v0; i = i0;
-    }
-    {
-        auto a = GE2E_SWAP32(__float_as_uint(v));
-        auto b = GE2E_SWAP32((unsigned)i);
-        float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
-        argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
-        v = v0; i = i0;
-    }
+__device__ __forceinline__ void mfma32x3(f32x16& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
+    mfma32(acc, ah, bh); mfma32(acc, ah, bl); mfma32(acc, al, bh);
+}
+// ... and the same blindness covers the OPERANDS: hipcc does not know that the asm reads A / B for several cycles after
+// issue (a dependent MFMA starts only when its predecessor's sum is there), so it happily reuses a fragment register
+// for a VALU temporary one instruction later (seen: v_add_u32 v6 right behind `v_mfma .., v[6:9], ..`), and the MFMA
+// multiplies with the temporary.  Every fragment register of a chain is therefore kept live (an empty asm that
+// "reads" it) until the chain's settle has passed.
+#define T2_KEEP(x) asm volatile("" :: "v"(x))
+#define T2_SETTLE16_1(a0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0))
+#define T2_SETTLE16_2(a0, a1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))            /* 16x16x32: 8 passes  */
+#define T2_SETTLE16_4(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
+#define T2_SETTLE32(a0, a1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))  /* 32x32x16: 16 passes */
+// results of an EARLIER chain may be read once a whole later chain has been issued behind it (the pipe is in order);
+// this empty statement keeps the compiler from moving such a read above the later chain's (volatile) MFMAs
+#define T2_AFTER_1(a0) asm volatile("" : "+v"(a0))
+#define T2_AFTER_2(a0, a1) asm volatile("" : "+v"(a0), "+v"(a1))
+__device__ __forceinline__ f32x4 acc_zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // a register, not the inline constant 0: the chain starts in its final home.  hipcc pads nothing around asm, so the
+    // wait states between these VALU writes and an (asm) MFMA reading them as SrcC are spelled out here: without them
+    // whole accumulator tiles started from the register's OLD contents whenever the wave issued back to back
+    asm volatile("s_nop 4" : "+v"(z));
+    return z;
+}
+
+// one lane waits; the result travels through an LDS word that is not reused for four waits (there is a
+// workgroup barrier between any two of them), so ONE barrier per wait is enough
+__device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned target, TeamCtl* ctl, int* sh, int& slot) {
+    int* w = sh + (slot & 3);
+    ++slot;
+    if (threadIdx.x == 0) *w = spin_until(counter, target, ctl) ? 1 : 0;
+    __syncthreads();
+    return *w != 0;
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-static int team_cu_count();
-
-bool team_supports(int N, int M, int D) {
-    if (!(N >= 1 && N <= NC && M >= 2 && M <= MAXM && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
-    if (team_cu_count() < MAX_XCD * TEAM) return false;      // partitioned device: no XCD-wide teams to form
-    return team_layout(N, M, D).lds_bytes <= 160 * 1024;
+static int team_cu_count() {   // queried on every call (no per-process cache: the current device may change)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;                // no device visible (build host): size queries answer for a whole MI355X
 }
 
-TeamWs team_layout(int N, int M, int D) {
-    TeamWs L;
+TeamKWs team_layout(int N, int M, int D) {
+    TeamKWs L{};
     L.spm = (N + TEAM - 1) / TEAM;
     L.rt = (L.spm * M + 15) / 16 * 16;
-    L.chx = 0;                                                // [2][64] rows of (D hi | D lo) halfs: unit centroids * 2^8
-    L.cstx = L.chx + (size_t)2 * NC * D;                      // [2][64][4]   rn, kappa, |s|, |s|^2
-    L.gcx = L.cstx + (size_t)2 * NC * 4;                      // [2][8][64][D] partial centroid gradients
-    L.scx = L.gcx + (size_t)2 * TEAM * NC * D;                // [2][8][4]    loss, dw, db partials
-    L.stride = align_up(L.scx + (size_t)2 * TEAM * 4, 64);
-    L.head_bytes = align_up(sizeof(TeamCtl) + 64 * sizeof(TeamFlags), 256);
-    const int PH = D + 16;
-    L.lds_bytes = (size_t)(2 * NC * PH + 2 * L.rt * PH) * 2 + (size_t)(L.rt * 8 + NC * 4 + 32 + 8) * sizeof(float);
+    L.mul_m = (65536 + M - 1) / M;
+    L.head_bytes = (unsigned)align_up(sizeof(TeamCtl) + 64 * sizeof(TeamKFlags), 256);
+    const int P = D + 16;
+    const size_t et = (size_t)2 * L.rt * P * 2;
+    size_t xb = (size_t)L.rt * XP * 4;                 // X half-blocks; the first also holds the KJ rows [8][D] of phase F,
+    if (xb < (size_t)8 * D * 4) xb = (size_t)8 * D * 4;   // the second stages the centroid for its k-group form:
+    if (xb < (size_t)2 * 8 * (D + STGPAD) * 2) xb = (size_t)2 * 8 * (D + STGPAD) * 2;   // [hi, lo][8 slots][D + 32] halfs
+    const size_t g = (size_t)2 * L.rt * GP * 2;        // G images
+    L.xb_bytes = (unsigned)xb;
+    L.g_bytes = (unsigned)g;
+    L.lds_bytes = et + 2 * xb + g + (size_t)(L.rt * 8 + NC * 4 + 32 + 16) * sizeof(float);
     return L;
 }
 
-static int team_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            cus = 256;
-    }
-    return cus;
+bool team_supports(int N, int M, int D) {
+    if (!(N >= 1 && N <= NC && M >= 2 && M <= 16 && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
+    const TeamKWs L = team_layout(N, M, D);
+    if (L.rt > RTMAX || L.lds_bytes > 160 * 1024) return false;
+    if (!fused_split_supports(N, M, D)) return false;            // the gated fall-back launch
+    return team_cu_count() >= MAX_XCD * TEAM;                    // partitioned device: no XCD-wide teams to form
 }
+
 // workgroups: one per CU, but no more than eight XCDs' worth of teams for the batches there are
 int team_grid(int B) {
     const int cus = team_cu_count() / (MAX_XCD * TEAM) * (MAX_XCD * TEAM);
     const long want = (long)((B + MAX_XCD - 1) / MAX_XCD) * (MAX_XCD * TEAM);
     return (int)(want < cus ? want : cus);
 }
+static size_t team_fb_bytes(int B, int N, int M, int D) {
+    const int g = B < TEAM_FALLBACK_GRID ? B : TEAM_FALLBACK_GRID;
+    return (size_t)g * fused_split_layout(N, M, D).stride * sizeof(float);
+}
 size_t team_workspace_bytes(int B, int N, int M, int D) {
-    const TeamWs L = team_layout(N, M, D);
-    return L.head_bytes + (size_t)(team_grid(B) / TEAM) * L.stride * sizeof(float);
+    const TeamKWs L = team_layout(N, M, D);
+    return align_up(L.head_bytes + (size_t)(team_grid(B) / TEAM) * team_exchange(D).stride, 256) + team_fb_bytes(B, N, M, D);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MR>  // D = 64 * NCH; MR >= M rows of a speaker are held in registers between batches
-__global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) {
+// D = 64 * NCH; MR >= M rows of a speaker are prefetched into registers; RBT > 0: the member's images have exactly
+// RBT 16-row blocks (compile-time trip counts for the metric shape), RBT == 0: L.rt / 16 at run time.
+template <int NCH, int MR, int RBT, bool CONTRAST>
+__global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
-    constexpr int PH = D + 16;            // image pitch: rows 8 banks apart, conflict-free for b128 row reads AND tr reads
+    constexpr int P = D + 16;             // image pitch: rows 8 banks apart (b128 row reads AND transposing reads)
     constexpr unsigned ROWB = D * 4;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
-    const int RT = L.rt;
-    _Float16* const CHh = reinterpret_cast<_Float16*>(smem_f);
-    _Float16* const CHl = CHh + NC * PH;
-    _Float16* const ETh = CHl + NC * PH;
-    _Float16* const ETl = ETh + RT * PH;
-    _Float16* const Gh = CHh;                                   // P6..P7: G images over the centroid images
+    constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
+    constexpr TeamKX XO = team_exchange(D);
+    constexpr int RBC = RBT ? RBT : RBMAX;
+    const int RB = RBT ? RBT : L.rt / 16;
+    const int RT = 16 * RB;
+    const int RBr = RB;
+    constexpr bool CT_X = RBT != 0, CT_S = RBT != 0, CT_DE = RBT != 0, CT_GC = RBT != 0;
+    _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
+    _Float16* const ETl = ETh + RT * P;
+    float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
+    float* const XB1 = XB0 + L.xb_bytes / 4;
+    _Float16* const Gh = reinterpret_cast<_Float16*>(XB1 + L.xb_bytes / 4);
     _Float16* const Gl = Gh + RT * GP;
-    float* const KJL = reinterpret_cast<float*>(CHh);           // P8: KJ_j rows [8][D] fp32 over the (dead) G images
-    float* const CJL = KJL + 8 * D;                             //     c-hat_j rows [8][D] fp32
-    float* const RS = reinterpret_cast<float*>(ETl + RT * PH);  // [RT][8]: rne ke ee | ra c1 rc c3 c4
-    float* const CST = RS + RT * 8;                             // [64][4]
-    float* const RED = CST + NC * 4;                            // [32]
-    int* const SH = reinterpret_cast<int*>(RED + 32);           // [8]
+    float* const RS = reinterpret_cast<float*>(reinterpret_cast<char*>(Gh) + L.g_bytes);   // [RT][8]
+    float* const CST = RS + RT * 8;                                // [64][4]  1/|c|, kappa, |s|, |s|^2 of every slot
+    float* const RED = CST + NC * 4;                               // [32]
+    int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
+    float* const KJ = XB0;                                         // F: KJ_j rows [8][D] (X has been consumed by then)
+    _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: centroid stage [hi, lo][8 slots][D + STGPAD]
+    constexpr int SP = D + STGPAD;
 
     const int N = p.N, M = p.M, NM = N * M;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int d4 = 4 * lane;
-    const bool dact = d4 < D;
-    const int kh = wid >> 2, sl = wid & 3;
-    const bool slice_on = 64 * sl < D;
 
     TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
-    TeamFlags* const flags = reinterpret_cast<TeamFlags*>(ctl + 1);
+    TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
     const TeamId id = team_form(ctl, SH);
-    if (id.nct == 0 && blockIdx.x == 0)   // no eight workgroups share an XCD: fail loudly
-        for (int i = tid; i < p.B; i += 512) p.loss[i] = __builtin_nanf("");
+    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the gated launch takes over
+        __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (id.team < 0) return;
-    TeamFlags* const fl = flags + id.team;
+    TeamKFlags* const fl = flags + id.team;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
-        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * L.stride * 4, (unsigned)(L.stride * 4));
+        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * XO.stride, XO.stride);
 
     const int spm = L.spm;
-    const int j0 = id.member * spm;
+    const int j0 = id.member * spm;                    // first speaker of this member
     const int my_spm = max(0, min(spm, N - j0));
     const int R_my = my_spm * M;
     const bool has_spk = wid < my_spm;
-    const int j = j0 + wid;                 // this wave's speaker (if has_spk)
-    const int rbase = wid * M;              // its first row in the ET / G images
+    const int j = j0 + wid;                            // this wave's speaker (if has_spk)
+    const int kslot = 8 * id.member + wid;             // ... and the slot every wave is responsible for in A
+    const int rbase = wid * M;                         // first row of that speaker in the images
 
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
-    const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
-    const float fM = (float)M, inv_m1 = 1.0f / (float)(M - 1);
-    const bool contrast = p.variant == 1;
+    const float eps = p.eps, eps_cos = p.eps_cos;
+    const float eps_cos2 = eps_cos * eps_cos;
+    const float fM = (float)M, inv_m = 1.0f / fM, inv_m1 = 1.0f / (float)(M - 1);
     const bool want_grad = p.dE != nullptr;
-    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
+    const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
+    // softmax in base 2: S2 = S log2(e)
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const float w2 = w * LOG2E, b2 = (w * eps + bias) * LOG2E, leps2 = p.log_eps * LOG2E;
 
-    // rows of the ET images that never receive an embedding stay zero (they are contracted over in P7)
-    for (int i = tid; i < RT * PH / 8; i += 512) {
+    // rows of the ET images that never receive an embedding stay zero (they are contracted over in GC)
+    for (int i = tid; i < RT * P / 8; i += 512) {
         reinterpret_cast<float4*>(ETh)[i] = zero4();
         reinterpret_cast<float4*>(ETl)[i] = zero4();
     }
+    for (int i = tid; i < RT * 2; i += 512) reinterpret_cast<float4*>(RS)[i] = zero4();   // rows without an embedding
     __syncthreads();
 
-    // Software pipeline over the team's batches.  VMEM retires in issue order and a hand-off costs a store
-    // drain plus a round trip, so the loop is rotated: an iteration starts batch `cur` (P1) BEFORE it finishes
-    // batch `prev` (P8), publishes both with ONE drain + barrier, and every wait sits behind work:
-    //
-    //   P1(cur)            rows (requested one iteration ago) -> ET images, centroid -> team
-    //   drain, barrier     signal hand-off 2 of prev (its gC partials were stored at the end of the last
-    //                      iteration) and hand-off 1 of cur
-    //   wait 2(prev), P8   gC partials of my speaker -> KJ_j -> the held dE rows of prev are complete
-    //   wait 1(cur), P2    centroids -> CH images
-    //   P3                 X; every K-step also stores two finished tiles of prev's dE (they trickle out under
-    //                      an LDS / MFMA-bound loop instead of blocking a phase, and free their registers)
-    //   P4 P5              softmax, gE -> the held part of cur's dE; then the rows of the NEXT batch are requested
-    //   P6 P7              G images, partial gC -> team (stores only; drained at the top of the next iteration)
     float4 rowv[MR];            // this wave's rows of the batch about to start
-    float4 dEp[NT];             // dE of the wave's rows: row 4 q + pq, columns 16 t + 4 cq15 ..  (P5 .. next P5)
-    float4 kjp = zero4();       // speaker row KJP_j of prev, this lane's 4 columns (P5 -> P8)
-    float4 cj_row = zero4();    // c-hat_j of prev, this lane's 4 columns
-    float rcs = 0.f;            // coefficient of c-hat_j in this lane's row of prev
-    float rn_j = 0.f, kap_j = 0.f;
-#define GE2E_TEAM_LOAD_ROWS(BI)                                                                          \
+    float4 held[NTI][RBC];      // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..   (GE -> next iteration)
+    float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                      (F -> next F)
+    float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
+    float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTI; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RBC; ++rb) held[i][rb] = zero4();
+
+#define GE2E_T2_LOAD_ROWS(BI)                                                                            \
     do {                                                                                                 \
+        int lq_ = lane;                                                                                  \
+        asm volatile("" : "+v"(lq_));                                                                    \
+        const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                  \
         const bool on_ = has_spk && (BI) < p.B;                                                          \
         const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
-            rowv[i] = bload4<GE2E_TEAM_E_AUX>(rs_, (on_ && i < M) ? vrow : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+            rowv[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
     } while (0)
+    // lane-derived indices are re-derived inside each phase from an opaque copy of the lane id (kept out of the
+    // loop-invariant set: hoisted they spill, and a scratch reload queues behind every VMEM operation in flight)
+#define GE2E_T2_LANE()                                                  \
+    int lv_ = lane;                                                     \
+    asm volatile("" : "+v"(lv_));                                       \
+    const int l15 = lv_ & 15, q = lv_ >> 4, d4 = 4 * lv_;               \
+    const bool dact = d4 < D;                                           \
+    (void)l15; (void)q; (void)d4; (void)dact
 
-    // Lane-derived indices are re-derived inside each phase from an opaque copy of the lane id.  As loop
-    // invariants they were hoisted out of the batch loop, spilled under the register peaks, and reloaded from
-    // scratch in the middle of phases -- and a scratch reload is a VMEM load that retires in order BEHIND the
-    // dE stores still in flight.  A handful of VALU ops per phase is far cheaper.
-#define GE2E_TEAM_LANE_IDS()                                                                        \
-    int lv_ = lane;                                                                                 \
-    asm volatile("" : "+v"(lv_));                                                                   \
-    const int l15 = lv_ & 15, q = lv_ >> 4, l31 = lv_ & 31, h = lv_ >> 5, pq = lv_ & 3;             \
-    const int cq15 = (lv_ & 15) >> 2, cq31 = (lv_ & 31) >> 2, d4 = 4 * lv_;                         \
-    const bool dact = d4 < D;                                                                       \
-    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                                           \
-    const int ir = 4 * q + pq;                                                                      \
-    const bool irv = ir < M;                                                                        \
-    const int irc = min(ir, M - 1);                                                                 \
-    const unsigned vo_de = irv ? (unsigned)((j * M + ir) * D + 4 * cq15) * 4u : OOB;                \
-    (void)l15; (void)q; (void)l31; (void)h; (void)pq; (void)cq15; (void)cq31; (void)dact; (void)vrow; \
-    (void)irc; (void)vo_de
-    // a bounded spin ran out (a member never arrived): make the failure loud in the outputs before leaving
-#define GE2E_TEAM_FAIL()                                                             \
-    do {                                                                             \
-        for (int i_ = tid; i_ < p.B; i_ += 512) p.loss[i_] = __builtin_nanf("");     \
-    } while (0)
-    GE2E_PROF_DECL(10)
-    GE2E_TEAM_LOAD_ROWS(id.team);
+    GE2E_PROF_DECL(12)
+    GE2E_T2_LOAD_ROWS(id.team);
+    int wslot = 0;
     bool failed = false;
     for (int seq = 0;; ++seq) {
         const int bi = id.team + seq * id.nct;          // batch started in this iteration
         const bool have_cur = bi < p.B, have_prev = seq > 0;
         if (!have_cur && !have_prev) break;
         const int buf = seq & 1, pbuf = buf ^ 1;
-        const unsigned offCH = (unsigned)((L.chx + (size_t)buf * NC * D) * 4);
-        const unsigned offCS = (unsigned)((L.cstx + (size_t)buf * NC * 4) * 4);
-        const unsigned offGC = (unsigned)((L.gcx + (size_t)buf * TEAM * NC * D) * 4);
-        const unsigned offSC = (unsigned)((L.scx + (size_t)buf * TEAM * 4) * 4);
-        const unsigned offGCp = (unsigned)((L.gcx + (size_t)pbuf * TEAM * NC * D) * 4);
-        const unsigned offSCp = (unsigned)((L.scx + (size_t)pbuf * TEAM * 4) * 4);
         const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
                                                        want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
+        cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
 
-        // ===== P1(cur): own rows -> ET images, unit centroid -> team ===================================
-        if (has_spk && have_cur) {
-            GE2E_TEAM_LANE_IDS();
-            // centroid first: its stores (and prev's partial gradients behind them) drain under the row work below
+        // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
+        if (have_cur) {
+            GE2E_T2_LANE();
             float4 s = zero4();
 #pragma unroll
             for (int i = 0; i < MR; ++i)
                 if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
-            const float4 c = make_float4(s.x / fM, s.y / fM, s.z / fM, s.w / fM);
+            const float4 c = scale4(s, inv_m);
             const float sq = wave_sum(dot4(c, c));
             const float ss = wave_sum(dot4(s, s));
-            float rn, kap;
-            unit_stats(sq, eps_cos, rn, kap);
-            {   // published as the finished fp16 images (row = D hi halfs, then D lo halfs): members only copy
-                h4 hi, lo;
-                split4(scale4(c, rn * kSplitScale), hi, lo);
+            float rn, kap, nc;
+            unit_stats_bf(sq, eps_cos, eps_cos2, rn, kap, nc);
+            if (!has_spk) { rn = 0.f; kap = 0.f; nc = 0.f; }     // slots without a speaker publish zero rows
+            cj_cur = has_spk ? scale4(c, rn) : zero4();
+            rn_cur = rn; kap_cur = kap;
+            h4 hi, lo;
+            split4(scale4(cj_cur, kSplitScale), hi, lo);
+            {   // row-major image row of slot kslot: D hi halfs, then D lo halfs
                 const unsigned vh = dact ? (unsigned)d4 * 2u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + offCH + (unsigned)j * ROWB, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + offCH + (unsigned)j * ROWB + 2u * D, 0, 0);
+                const unsigned o = XO.chr[buf] + (unsigned)kslot * ROWB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + o + 2u * D, 0, 0);
             }
-            // 1/max(|c|,eps), kappa, |s_j| scale (s_j = c-hat_j * that), |s_j|^2
-            bstore4(rsX, lane == 0 ? 0u : OOB, offCS + (unsigned)j * 16u, make_float4(rn, kap, fM / rn, ss));
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                if (i < M) {
-                    const float4 e = rowv[i];
-                    const float ee = wave_sum(dot4(e, e));
-                    float rne, ke;
-                    unit_stats_fast(ee, eps_cos, rne, ke);
-                    if (dact) put_split4(ETh, ETl, (rbase + i) * PH + d4, scale4(e, rne * kSplitScale));
-                    if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, 0.f);
-                }
+            if (dact) {   // one 8-byte write per image: a row of the stage per wave
+                *reinterpret_cast<h4*>(STG + wid * SP + d4) = hi;
+                *reinterpret_cast<h4*>(STG + (8 + wid) * SP + d4) = lo;
             }
+            // 1/max(|c|,eps), kappa, |s_j| (s_j = c-hat_j * that), |s_j|^2
+            bstore4(rsX, lane == 0 ? XO.cst[buf] + (unsigned)kslot * 16u : OOB,
+                                    make_float4(rn, kap, has_spk ? fM * nc : 0.f, has_spk ? ss : 0.f));
+        }
+        __syncthreads();
+        if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d), gathered
+            // by the transposing LDS read (4 slots x 16 columns per 16 lanes, twice); whole waves only (2 D % 64 == 0)
+            const int hl = tid >= D, d = tid - hl * D;
+            const int l16 = tid & 15;
+            const _Float16* p0 = STG + (8 * hl + (l16 >> 2)) * SP + (d - l16) + 4 * (l16 & 3);
+            const h4 a = tr_read4(p0), b2 = tr_read4(p0 + 4 * SP);
+            const h8 v = __builtin_shufflevector(a, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            bstore4(rsX, XO.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, __builtin_bit_cast(float4, v));
         }
         // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -341,426 +381,535 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamWs L) 
         }
         GE2E_PROF(0);
 
-        // ===== P8(prev): batch scalars; own speaker's gC -> KJ_j; the held rows of dE become complete ==
-        if (have_prev) {
-            if (!team_wait(&fl->c2, (unsigned)(TEAM * seq), ctl, SH + 4)) { failed = true; break; }
-            GE2E_PROF(8);
-            if (id.member == 0 && tid == 0) {
-                float l = 0.f, a = 0.f, c = 0.f;
-                for (int m = 0; m < TEAM; ++m) {
-                    const float4 v = bload4<AUX_L2>(rsX, 0u, offSCp + (unsigned)m * 16u);
-                    l += v.x; a += v.y; c += v.z;
+        // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
+        if (have_cur && has_spk) {
+            GE2E_T2_LANE();
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                if (i < M) {
+                    const float4 e = rowv[i];
+                    const float ee = wave_sum(dot4(e, e));
+                    float rne, ke, ne;
+                    unit_stats_bf(ee, eps_cos, eps_cos2, rne, ke, ne);
+                    if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));
+                    if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, ne);
                 }
-                if (p.loss) p.loss[bi - id.nct] = l;
-                if (p.dw) p.dw[bi - id.nct] = a;
-                if (p.db) p.db[bi - id.nct] = c;
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
-            if (want_grad && has_spk) {
-                GE2E_TEAM_LANE_IDS();
-                float4 part[TEAM];
-#pragma unroll
-                for (int m = 0; m < TEAM; ++m) part[m] = bload4<AUX_L2>(rsX, vrow, offGCp + (unsigned)(m * NC + j) * ROWB);
-                float4 gsum = part[0];
-#pragma unroll
-                for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
-                const float coefc = wave_sum(dot4(gsum, cj_row));
-                const float f = kap_j * coefc, sc = rn_j / fM;
-                if (dact) {
-                    *reinterpret_cast<float4*>(KJL + wid * D + d4) =
-                        make_float4((gsum.x - f * cj_row.x) * sc + kjp.x, (gsum.y - f * cj_row.y) * sc + kjp.y,
-                                    (gsum.z - f * cj_row.z) * sc + kjp.z, (gsum.w - f * cj_row.w) * sc + kjp.w);
-                    *reinterpret_cast<float4*>(CJL + wid * D + d4) = cj_row;
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {      // dE_r = held part + rc c-hat_j + KJ_j
-                    const float4 kj = *reinterpret_cast<const float4*>(KJL + wid * D + 16 * t + 4 * cq15);
-                    const float4 cj = *reinterpret_cast<const float4*>(CJL + wid * D + 16 * t + 4 * cq15);
-                    dEp[t].x += kj.x + rcs * cj.x; dEp[t].y += kj.y + rcs * cj.y;
-                    dEp[t].z += kj.z + rcs * cj.z; dEp[t].w += kj.w + rcs * cj.w;
-                }
-            }
-            GE2E_PROF(9);
         }
-        if (!have_cur) {   // drain: the last batch's rows go out in one piece
-            if (want_grad && has_spk) {
-                GE2E_TEAM_LANE_IDS();
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bstore4<AUX_NT>(rsGp, vo_de, 64u * t, dEp[t]);
-            }
-            break;
-        }
-
-        // ===== P2(cur): the 64 published unit centroids -> CH images (slots >= N are zero) ==============
-        if (!team_wait(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl, SH + 4)) { failed = true; break; }
         GE2E_PROF(1);
+
+        // ===== W: both hand-offs (signalled by every member at the same point) ======================================
         {
-            GE2E_TEAM_LANE_IDS();
-            float4 cv[8];     // 8 halfs of a published image row per lane: lanes below D / 8 hold hi, the next D / 8 lo
-            const bool cact = 8 * lane < 2 * D;
-            const bool chi = 8 * lane < D;
-            const int ccol = chi ? 8 * lane : 8 * lane - D;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = wid + 8 * u;
-                cv[u] = bload4<AUX_L2>(rsX, (k < N && cact) ? (unsigned)lane * 16u : OOB, offCH + (unsigned)min(k, N - 1) * ROWB);
+            int* const wsh = SH + 4 + (wslot & 3);
+            ++wslot;
+            if (tid == 0) {
+                bool ok = true;
+                if (have_cur) ok = spin_until(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl);
+                if (ok && have_prev) ok = spin_until(&fl->c2, (unsigned)(TEAM * seq), ctl);
+                *wsh = ok ? 1 : 0;
             }
-            float4 cst = zero4();
-            if (tid < NC) cst = bload4<AUX_L2>(rsX, tid < N ? (unsigned)tid * 16u : OOB, offCS);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (cact) *reinterpret_cast<float4*>((chi ? CHh : CHl) + (wid + 8 * u) * PH + ccol) = cv[u];
-            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cst;
+            __syncthreads();                 // also: every wave's ET rows and row scalars are written
+            if (*wsh == 0) { failed = true; break; }
         }
-        __syncthreads();
         GE2E_PROF(2);
 
-        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        GFrag gf;                   // dL/dS (own column removed) * 2^8 of this lane's 16 columns as fp16 hi / lo: the A
-                                    // operand of P5 and, bit for bit, what P6 writes as the G images
-        if (has_spk) {
-            GE2E_TEAM_LANE_IDS();
-            // ===== P3: X[k][r] for the wave's own rows ================================================
-            const int irow = min(l15, M - 1);
-            const bool rv = l15 < M;
-            f32x4 acc[4];
+        // ===== B: centroid fragments, previous batch's partial gradients and scalars -> registers ===================
+        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
+        h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
+        float4 part[TEAM];
+        float4 cstv = zero4(), scv = zero4();
+        {
+            GE2E_T2_LANE();
+            if (have_cur) {
+                const unsigned oa = XO.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-            {   // gemm_x_16rows, with the finished dE tiles of prev trickling out: two 16-byte stores per K-step
-                // under an LDS / MFMA-bound loop (dropped by the out-of-range offset when there is nothing to store)
-                const int off_a = l15 * PH + 8 * q;
-                const int off_b = (rbase + irow) * PH + 8 * q;
-#pragma unroll
-                for (int s = 0; s < D / 32; ++s) {
-                    const h8 bh = frag_row(ETh + off_b + 32 * s), bl = frag_row(ETl + off_b + 32 * s);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t] = mfma3_16(frag_row(CHh + off_a + 16 * t * PH + 32 * s), frag_row(CHl + off_a + 16 * t * PH + 32 * s),
-                                          bh, bl, acc[t]);
-                    bstore4<AUX_NT>(rsGp, vo_de, 64u * (2 * s), dEp[2 * s]);
-                    bstore4<AUX_NT>(rsGp, vo_de, 64u * (2 * s + 1), dEp[2 * s + 1]);
+                for (int s = 0; s < NCH; ++s) {
+                    xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
+                    xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
                 }
+                if (tid < NC) cstv = bload4<AUX_L2>(rsX, XO.cst[buf] + (unsigned)tid * 16u, 0);
             }
-            GE2E_PROF(3);
-
-            f32x4 g[4];
-            // ===== P4: leave-one-out statistics, S, loss, G = dL/dS ===================================
-            const float4 rs0 = *reinterpret_cast<const float4*>(RS + (rbase + irow) * 8);  // rne ke ee
-            const float rne = rv ? rs0.x : 0.f, ke = rs0.y, ee = rs0.z;
-            const float4 cs = *reinterpret_cast<const float4*>(CST + j * 4);                // rn kap |s| |s|^2
-            float xo = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (16 * t + 4 * q + e == j) xo = acc[t][e];
-            xo = col4_sum(xo) * kSplitInv2;                  // c-hat_j . e-hat_r
-            const float rne1 = rv ? rs0.x : 1.0f;
-            const float es = xo * cs.z / rne1;               // e . s_j
-            const float eu = (es - ee) * inv_m1;
-            const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
-            float rnu, ku;
-            unit_stats_fast(uu, eps_cos, rnu, ku);
-            const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
-            const float sjj = w * (cosd + eps) + bias;
-            float c0[4][4], sv[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 16 * t + 4 * q + e;
-                    c0[t][e] = (k == j) ? cosd : acc[t][e] * kSplitInv2;
-                    sv[t][e] = (k < N) ? w * (c0[t][e] + eps) + bias : -INFINITY;
-                }
-            float per;
-            if (!contrast) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sv[t][e]);
-                mx = fmaxf(col4_max(mx), log_eps);
-                float zoff = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        g[t][e] = __expf(sv[t][e] - mx);   // exp(-inf) = 0 for unused slots
-                        if (16 * t + 4 * q + e != j) zoff += g[t][e];
-                    }
-                zoff = col4_sum(zoff) + __expf(log_eps - mx);
-                const float z = zoff + __expf(sjj - mx);
-                per = (mx - sjj) + __logf(z);
-                const float rz = 1.0f / z;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        g[t][e] = (16 * t + 4 * q + e == j) ? -zoff * rz : g[t][e] * rz;   // 1 - p_jj = z_off / z
-            } else {
-                float best = -INFINITY; int besti = 0x7fffffff;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 16 * t + 4 * q + e;
-                        if (k != j && sv[t][e] > best) { best = sv[t][e]; besti = k; }
-                    }
-                col4_argmax(best, besti);
-                const float pos = 1.0f / (1.0f + __expf(-sjj));
-                const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best)) : 0.0f;
-                per = 1.0f - pos + neg;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 16 * t + 4 * q + e;
-                        g[t][e] = (k == j) ? -pos * (1.0f - pos) : ((k == besti) ? neg * (1.0f - neg) : 0.f);
-                    }
-            }
-            float coef = 0.f, ad = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 16 * t + 4 * q + e;
-                    if (!rv || k >= N) g[t][e] = 0.f;
-                    dw_acc += g[t][e] * (c0[t][e] + eps);
-                    db_acc += g[t][e];
-                    coef += g[t][e] * c0[t][e];     // (dL/d e-hat) . e-hat / w, own-speaker term included
-                    if (k == j) { ad = g[t][e]; g[t][e] = 0.f; }
-                }
-            coef = w * col4_sum(coef);
-            ad = w * col4_sum(ad);                  // dL/dcos on the own-speaker column
-            GE2E_PROF(4);
-            if (rv && q == 0) {
-                loss_acc += per;
-                if (p.per) p.per[(size_t)bi * NM + j * M + l15] = per;
-            }
-            if (want_grad) {
-                // dE_r = ra acc + c1 e-hat + rc c-hat_j + KJ_j   (ge2e_fused_f32.hip header for the algebra)
-                const float rho = rnu * inv_m1;
-                const float c2 = rho * (ad * rne1 + ad * ku * cosd * rnu * inv_m1);
-                const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
-                const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
-                const float beta = -ad * rnu * ku * cosd * rho;
-                if (rv && q == 0) {
-                    float* r8 = RS + (rbase + l15) * 8;
-                    r8[3] = rne * (w * kSplitInv2);           // of the gE accumulator (carries 2^16)
-                    r8[4] = c1 * kSplitInv;                   // of the e-hat image value (carries 2^8)
-                    r8[5] = c2 * cs.z;                        // of c-hat_j (applied in P8)
-                }
-                // speaker row KJP_j (this lane's 4 columns).  The row coefficients sit in lane i (= row i) of every
-                // 16-lane group: c3_i is broadcast with v_readlane, sum_i c4_i is a 16-lane DPP sum -- no LDS trip,
-                // and the M image rows are requested back to back.
-                const float c3v = alpha * inv_m1 * kSplitInv, c4v = rv ? beta * inv_m1 : 0.f;
-                const float bsum = row16_sum(c4v);
-                kjp = zero4();
-                cj_row = dact ? scale4(get_join4(CHh, CHl, j * PH + d4), kSplitInv) : zero4();
-#pragma unroll
-                for (int i0 = 0; i0 < MR; i0 += 4) {          // four rows in flight (8 VGPRs of fragments)
-                    h4 eh[4], el[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int off = (rbase + min(i0 + u, M - 1)) * PH + min(d4, D - 4);
-                        eh[u] = *reinterpret_cast<const h4*>(ETh + off);
-                        el[u] = *reinterpret_cast<const h4*>(ETl + off);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (i0 + u < MR) {
-                            const float c3 = i0 + u < M ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3v), i0 + u)) : 0.f;
-                            kjp.x = fmaf((float)eh[u][0], c3, fmaf((float)el[u][0], c3, kjp.x));
-                            kjp.y = fmaf((float)eh[u][1], c3, fmaf((float)el[u][1], c3, kjp.y));
-                            kjp.z = fmaf((float)eh[u][2], c3, fmaf((float)el[u][2], c3, kjp.z));
-                            kjp.w = fmaf((float)eh[u][3], c3, fmaf((float)el[u][3], c3, kjp.w));
-                        }
-                    }
-                }
-                if (!dact) kjp = zero4();
-                const float bs = bsum * cs.z;
-                kjp.x += bs * cj_row.x; kjp.y += bs * cj_row.y; kjp.z += bs * cj_row.z; kjp.w += bs * cj_row.w;
-                // ===== P5: gE = G . CH from registers; ra gE + c1 e-hat stays in registers =============
-                f32x4 gs[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gs[t][e] = g[t][e] * kSplitScale;
-                gf = g_to_frag(gs);
-                const float* r8 = RS + (rbase + irc) * 8;
-                const float ra = irv ? r8[3] : 0.f, c1i = irv ? r8[4] : 0.f;
-                rcs = irv ? r8[5] : 0.f;
-                // Three tiles are in flight, written out by hand because the compiler serialises the chain
-                // (LDS -> wait -> 6 dependent MFMAs -> wait -> transpose / epilogue, ~1000 cycles a tile): the
-                // fragments of tile t + 1 are requested, then the MFMAs of tile t issue, then the VALU epilogue
-                // of tile t - 1 runs underneath them.
-                h8 fb[2][4];        // [parity][CH hi K-step 0, lo 0, hi 1, lo 1]
-                h4 ee[3][2];        // [tile % 3][e-hat hi, lo] of this lane's row, 4 columns (live across three stages)
-                f32x4 ot[2];
-                const int eoff0 = (rbase + irc) * PH + 4 * cq15;
-#define GE2E_TEAM_P5_LOAD(T)                                                                     \
-    do {                                                                                         \
-        fb[(T) & 1][0] = frag_tr16(CHh, PH, 0, 16 * (T), lv_);                                  \
-        fb[(T) & 1][1] = frag_tr16(CHl, PH, 0, 16 * (T), lv_);                                  \
-        fb[(T) & 1][2] = frag_tr16(CHh, PH, 1, 16 * (T), lv_);                                  \
-        fb[(T) & 1][3] = frag_tr16(CHl, PH, 1, 16 * (T), lv_);                                  \
-        ee[(T) % 3][0] = *reinterpret_cast<const h4*>(ETh + eoff0 + 16 * (T));                   \
-        ee[(T) % 3][1] = *reinterpret_cast<const h4*>(ETl + eoff0 + 16 * (T));                   \
-    } while (0)
-#define GE2E_TEAM_P5_EPI(T)                                                                      \
-    do {                                                                                         \
-        float x_[4] = {ot[(T) & 1][0], ot[(T) & 1][1], ot[(T) & 1][2], ot[(T) & 1][3]};          \
-        quad_transpose4(x_, lv_);                                                               \
-        const h4 eh_ = ee[(T) % 3][0], el_ = ee[(T) % 3][1];                                     \
-        dEp[T] = make_float4(fmaf((float)eh_[0], c1i, fmaf((float)el_[0], c1i, x_[0] * ra)),    \
-                             fmaf((float)eh_[1], c1i, fmaf((float)el_[1], c1i, x_[1] * ra)),    \
-                             fmaf((float)eh_[2], c1i, fmaf((float)el_[2], c1i, x_[2] * ra)),    \
-                             fmaf((float)eh_[3], c1i, fmaf((float)el_[3], c1i, x_[3] * ra)));   \
-    } while (0)
-                GE2E_TEAM_P5_LOAD(0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (t + 1 < NT) GE2E_TEAM_P5_LOAD(t + 1);
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma3_16(gf.hi[0], gf.lo[0], fb[t & 1][0], fb[t & 1][1], o);
-                    o = mfma3_16(gf.hi[1], gf.lo[1], fb[t & 1][2], fb[t & 1][3], o);
-                    if (t > 0) GE2E_TEAM_P5_EPI(t - 1);
-                    ot[t & 1] = o;
-                }
-                GE2E_TEAM_P5_EPI(NT - 1);
-                rn_j = cs.x; kap_j = cs.y;
+            if (have_prev) {
+                if (id.member == 0 && tid < TEAM) scv = bload4<AUX_L2>(rsX, XO.sc[pbuf] + (unsigned)tid * 16u, 0);
             }
         }
 
-        GE2E_TEAM_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under P6 / P7 and the hand-offs
-        // ---- member scalars: fixed-order reduction over the 8 waves ----------------------------------
+        // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
+        if (have_cur) {
+            GE2E_T2_LANE();
+            float* const XBk = khX ? XB1 : XB0;
+            const int off0 = l15 * P + 32 * khX * NCH + 8 * q;
+            h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
+            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
+#define T2_X_LOAD(T_)                                                                                     \
+    do {                                                                                                  \
+        fb[(T_) & 1][0] = frag_row(ETh + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+        fb[(T_) & 1][1] = frag_row(ETl + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+    } while (0)
+#define T2_X_STORE(RB_)                                                                       \
+    *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
+        make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
+            T2_X_LOAD(0);
+#pragma unroll
+            for (int rb = 0; rb < RBC; ++rb) {
+                if (CT_X || rb < RBr) {
+                    acc[rb & 1] = acc_zero4();
+#pragma unroll
+                    for (int s = 0; s < NCH; ++s) {
+                        const int t = rb * NCH + s;
+                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
+                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
+                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+                    }
+                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
+                    if (rb > 0) { T2_AFTER_1(acc[(rb & 1) ^ 1]); T2_X_STORE(rb - 1); }
+                }
+            }
+            T2_SETTLE16_2(acc[0], acc[1]);
+            T2_KEEP(fb[0][0]); T2_KEEP(fb[0][1]); T2_KEEP(fb[1][0]); T2_KEEP(fb[1][1]);
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) { T2_KEEP(xa[s][0]); T2_KEEP(xa[s][1]); }
+            if (CT_X) { T2_X_STORE(RBT - 1); }
+            else {
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb)
+                    if (rb == RBr - 1) { T2_X_STORE(rb); }
+            }
+#undef T2_X_LOAD
+#undef T2_X_STORE
+            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
+        }
+        // ---- previous batch: scalars out ----------------------------------------------------------------------------
+        if (have_prev) {
+            if (id.member == 0 && wid == 0) {
+                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+                if (lane == 0) {
+                    if (p.loss) p.loss[bi - id.nct] = l;
+                    if (p.dw) p.dw[bi - id.nct] = a;
+                    if (p.db) p.db[bi - id.nct] = c;
+                }
+            }
+        }
+        __syncthreads();
+        GE2E_PROF(3);
+
+        // ===== S(cur): leave-one-out statistics, S, loss, dL/dS -> G images, row coefficients =======================
+        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        if (have_cur) {
+            GE2E_T2_LANE();
+            const int c4 = 4 * l15;
+            const int nval = max(0, min(spm, N - (l15 >> 1) * spm));   // valid slots of the member this lane's columns belong to
+            const int kl = 4 * (l15 & 1);                              // slot index of column 0 inside its member
+            const bool kv0 = kl < nval, kv1 = kl + 1 < nval, kv2 = kl + 2 < nval, kv3 = kl + 3 < nval;
+            const int npass = CT_S ? RT / 4 : RBr * 4;
+#pragma unroll
+            for (int k = 0; k < (RBC * 4 + 7) / 8; ++k) {
+                const int pi = wid + 8 * k;
+                if (pi < npass) {
+                    const int r = 4 * pi + q;
+                    const bool rv = r < R_my;
+                    const int loc = min((r * L.mul_m) >> 16, 7);
+                    const int ko = 8 * id.member + loc;                    // own-speaker slot of this row
+                    const int dk = ko - c4;                                // own column = entry dk of this lane (if 0..3)
+                    const float4 x0 = *reinterpret_cast<const float4*>(XB0 + r * XP + c4);
+                    const float4 x1 = *reinterpret_cast<const float4*>(XB1 + r * XP + c4);
+                    const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
+                    const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee |e|
+                    const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
+                    const float rne = rs0.x, ke = rs0.y, ee = rs0.z, ne = rs0.w;        // all zero for rows without an embedding
+                    const float es = xo * cs.z * ne;                 // e . s_j
+                    const float eu = (es - ee) * inv_m1;
+                    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+                    float rnu, ku, nu;
+                    unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
+                    const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+                    const float sjj2 = fmaf(w2, cosd, b2);
+                    float c0[4], g[4];
+                    c0[0] = dk == 0 ? cosd : (x0.x + x1.x) * kSplitInv2;
+                    c0[1] = dk == 1 ? cosd : (x0.y + x1.y) * kSplitInv2;
+                    c0[2] = dk == 2 ? cosd : (x0.z + x1.z) * kSplitInv2;
+                    c0[3] = dk == 3 ? cosd : (x0.w + x1.w) * kSplitInv2;
+                    float per, ad0;
+                    if (!CONTRAST) {
+                        float sv[4];
+                        sv[0] = kv0 ? fmaf(w2, c0[0], b2) : -INFINITY;
+                        sv[1] = kv1 ? fmaf(w2, c0[1], b2) : -INFINITY;
+                        sv[2] = kv2 ? fmaf(w2, c0[2], b2) : -INFINITY;
+                        sv[3] = kv3 ? fmaf(w2, c0[3], b2) : -INFINITY;
+                        float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+                        mx = fmaxf(row16_max(mx), leps2);
+                        float zoff = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            g[e] = __builtin_amdgcn_exp2f(sv[e] - mx);   // 2^-inf = 0 for unused slots
+                            zoff += dk == e ? 0.f : g[e];
+                        }
+                        zoff = row16_sum(zoff) + __builtin_amdgcn_exp2f(leps2 - mx);
+                        const float z = zoff + __builtin_amdgcn_exp2f(sjj2 - mx);
+                        per = LN2 * ((mx - sjj2) + __builtin_amdgcn_logf(z));
+                        const float rz = rcp_nr(z);
+                        ad0 = rv ? -zoff * rz : 0.f;                 // dL/dS on the own-speaker column: -(1 - p_jj) = -z_off / z
+                        const float rzv = rv ? rz : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : g[e] * rzv;
+                    } else {
+                        float best = -INFINITY; int besti = 0x7fffffff;
+                        const bool kv[4] = {kv0, kv1, kv2, kv3};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sve = kv[e] ? fmaf(w2, c0[e], b2) : -INFINITY;
+                            if (dk != e && sve > best) { best = sve; besti = c4 + e; }
+                        }
+                        row16_argmax(best, besti);
+                        const float pos = rcp_nr(1.0f + __builtin_amdgcn_exp2f(-sjj2));
+                        const float neg = (N > 1) ? rcp_nr(1.0f + __builtin_amdgcn_exp2f(-best)) : 0.0f;
+                        per = 1.0f - pos + neg;
+                        ad0 = rv ? -pos * (1.0f - pos) : 0.f;
+                        const float gn = rv ? neg * (1.0f - neg) : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : ((c4 + e == besti && kv[e]) ? gn : 0.f);
+                    }
+                    float coef = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dw_acc = fmaf(g[e], c0[e] + eps, dw_acc);
+                        db_acc += g[e];
+                        coef = fmaf(g[e], c0[e], coef);       // (dL/d e-hat) . e-hat / w, own-speaker term included
+                    }
+                    if (rv && l15 == 0) {
+                        loss_acc += per;
+                        if (p.per) p.per[(size_t)bi * NM + j0 * M + r] = per;
+                    }
+                    if (want_grad) {
+                        coef = w * row16_sum(coef);
+                        // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
+                        // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
+                        // of s_j (o, in units of ra) without dividing by w
+                        const float ad = w * ad0;
+                        const float rho = rnu * inv_m1;
+                        const float t1 = ku * cosd * rho;                        // kappa_u cos rho
+                        const float c2_0 = rho * ad0 * (rne + t1);               // c2 / w
+                        const float c1 = -ke * coef * rne - ad * rho - w * c2_0 * ne;
+                        const float alpha = ad * rnu * (1.0f + t1 * ne);
+                        const float beta = -ad * rnu * t1;
+                        const float o = c2_0 * cs.z * ne;
+                        // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
+                        // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
+                        const float lam = cs.x * inv_m * w;
+                        if (l15 == 0)
+                            *reinterpret_cast<float4*>(RS + r * 8 + 4) =
+                                make_float4(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
+                                            c1 * kSplitInv,                                 // c1: of the e-hat image value (2^8)
+                                            (alpha * inv_m1 - lam * o) * kSplitInv,         // c3'
+                                            beta * inv_m1 * cs.z + lam * cs.y * o * xo);    // c4' (of c-hat_j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = (dk == e ? o : g[e]) * kSplitScale;
+                        put_split4(Gh, Gl, r * GP + c4, make_float4(g[0], g[1], g[2], g[3]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaved passes cost more registers than there are
+            }
+        }
+        // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
         loss_acc = wave_sum(loss_acc);
         dw_acc = wave_sum(dw_acc);
         db_acc = wave_sum(db_acc);
         if (lane == 0) { RED[wid] = loss_acc; RED[8 + wid] = dw_acc; RED[16 + wid] = db_acc; }
-        __syncthreads();                                   // also: every wave is done with the CH images
-        GE2E_PROF(5);
-        if (tid == 0) {
+        __syncthreads();
+        GE2E_PROF(4);
+
+        // ===== F: member scalars out; KJ_j of prev (its partial gradients have arrived) and KJP'_j of cur ===========
+        // first the requests whose answers are needed a phase or more from now: GE's centroid fragments (k-group form)
+        // and the next batch's rows (in flight under GC / GE and the next A1)
+        {
+            GE2E_T2_LANE();
+            if (have_prev && want_grad && has_spk) {      // my speaker's eight partial gradients (they land under KJP below)
+                const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
+#pragma unroll
+                for (int m = 0; m < TEAM; ++m)
+                    part[m] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
+            }
+        }
+        if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
-            bstore4(rsX, 0u, offSC + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
+            bstore4(rsX, XO.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
+        if (want_grad && has_spk) {
+            GE2E_T2_LANE();
+            const float4 kjp_prev = kjp;
+            if (have_cur) {   // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
+                kjp = zero4();
+                const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
+                const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    if (i < M) {
+                        const float c3 = RS[(rbase + i) * 8 + 6];
+                        const int off = (rbase + i) * P + min(d4, D - 4);
+                        const h4 eh = *reinterpret_cast<const h4*>(ETh + off), el = *reinterpret_cast<const h4*>(ETl + off);
+                        kjp.x = fmaf((float)eh[0], c3, fmaf((float)el[0], c3, kjp.x));
+                        kjp.y = fmaf((float)eh[1], c3, fmaf((float)el[1], c3, kjp.y));
+                        kjp.z = fmaf((float)eh[2], c3, fmaf((float)el[2], c3, kjp.z));
+                        kjp.w = fmaf((float)eh[3], c3, fmaf((float)el[3], c3, kjp.w));
+                    }
+                }
+                kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
+                if (!dact) kjp = zero4();
+            }
+            if (have_prev) {
+                float4 gsum = part[0];
+#pragma unroll
+                for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+                // every partial of this speaker has been read (the sums above waited for them; nothing of this wave's
+                // is behind them that the counted wait would have to skip): the single gC buffer may be rewritten
+                asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
+                if (lane == 0) add_agent(&fl->c3, 1u);
+                gsum = scale4(gsum, w * kSplitInv2);
+                const float coefc = wave_sum(dot4(gsum, cj_prev));
+                const float f = kap_prev * coefc, sc = rn_prev * inv_m;
+                if (dact)
+                    *reinterpret_cast<float4*>(KJ + wid * D + d4) =
+                        make_float4((gsum.x - f * cj_prev.x) * sc + kjp_prev.x, (gsum.y - f * cj_prev.y) * sc + kjp_prev.y,
+                                    (gsum.z - f * cj_prev.z) * sc + kjp_prev.z, (gsum.w - f * cj_prev.w) * sc + kjp_prev.w);
+            }
+        }
+        if (want_grad) __syncthreads();
+        GE2E_PROF(5);
 
-        if (want_grad) {
-            // ===== P6: G images (fp16 hi / lo, row-major [row][slot]) over the centroid images ========
-            if (has_spk) {
-                GE2E_TEAM_LANE_IDS();
-                if (l15 < M) {
+        if (want_grad && have_prev) {
+            // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ============
+            // The sums are formed IN the held registers and stored from there: nothing writes those registers again
+            // before the next GE.  A store's data registers must not be reused soon after it: with the memory pipe backed
+            // up (ten 16-byte stores per lane here) a queued store reads its data late, and an LDS read returning into the
+            // same registers meanwhile is not held back -- whole 16 x 16 tiles of the LAST stores of this loop came out
+            // with the next tile's KJ values in 5-20 % of the launches when the sum lived in a reused temporary.
+            GE2E_T2_LANE();
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {      // K-step s2 of the fragment = column blocks 2 s2 and 2 s2 + 1
-                    const uint4 hh = __builtin_bit_cast(uint4, gf.hi[s2]), ll = __builtin_bit_cast(uint4, gf.lo[s2]);
-                    _Float16* gh = Gh + (rbase + l15) * GP + 32 * s2 + 4 * q;
-                    _Float16* gl = Gl + (rbase + l15) * GP + 32 * s2 + 4 * q;
-                    *reinterpret_cast<uint2*>(gh) = make_uint2(hh.x, hh.y);
-                    *reinterpret_cast<uint2*>(gh + 16) = make_uint2(hh.z, hh.w);
-                    *reinterpret_cast<uint2*>(gl) = make_uint2(ll.x, ll.y);
-                    *reinterpret_cast<uint2*>(gl + 16) = make_uint2(ll.z, ll.w);
-                }
-                }
-            }
-            for (int i = tid; i < (RT - R_my) * (GP / 8); i += 512) {    // rows without an embedding
-                const int r = R_my + i / (GP / 8), c8 = (i % (GP / 8)) * 8;
-                *reinterpret_cast<float4*>(Gh + r * GP + c8) = zero4();
-                *reinterpret_cast<float4*>(Gl + r * GP + c8) = zero4();
-            }
-            __syncthreads();
-            GE2E_PROF(6);
-            // ===== P7: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ==
-            f32x16 gc[2];
+            for (int i = 0; i < NTI; ++i) {
+                const int dt = wid + 8 * i;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
-            if (slice_on) {
-                GE2E_TEAM_LANE_IDS();
-                for (int s = 0; s < RT / 16; ++s) {
-                    const h8 ah = frag_tr(Gh, GP, 16 * s, 32 * kh, lv_), al = frag_tr(Gl, GP, 16 * s, 32 * kh, lv_);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        gc[b] = mfma3(ah, al, frag_tr(ETh, PH, 16 * s, 64 * sl + 32 * b, lv_),
-                                      frag_tr(ETl, PH, 16 * s, 64 * sl + 32 * b, lv_), gc[b]);
-                }
-            }
-            if (slice_on) {
-                const float sc = w * kSplitInv2;
-                // The store offsets are recomputed from an opaque copy of the lane id: as loop invariants they
-                // were hoisted, spilled, and every reload then waited for ALL outstanding memory operations
-                // (scratch is VMEM too) -- eight full round trips in a row.
-                int lv = lane;
-                asm volatile("" : "+v"(lv));
-                const int k0 = 32 * kh + 4 * (lv >> 5) + (lv & 3);
-                const unsigned c0b = (unsigned)(64 * sl + 4 * ((lv & 31) >> 2)) * 4u + offGC + (unsigned)id.member * (NC * ROWB);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int k = k0 + 8 * g4;
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        float x[4] = {gc[b][4 * g4], gc[b][4 * g4 + 1], gc[b][4 * g4 + 2], gc[b][4 * g4 + 3]};
-                        quad_transpose4(x, lv);
-                        bstore4(rsX, k < N ? (unsigned)k * ROWB + c0b : OOB, 128u * b,
-                                make_float4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc));
+                for (int rb = 0; rb < RBC; ++rb) {
+                    if (CT_DE || rb < RBr) {
+                        const int r = 16 * rb + l15;
+                        const int loc = min((r * L.mul_m) >> 16, 7);
+                        const float4 kj = *reinterpret_cast<const float4*>(KJ + loc * D + min(16 * dt, D - 16) + 4 * q);
+                        const bool ok = r < R_my && dt < NT;
+                        held[i][rb].x += kj.x; held[i][rb].y += kj.y; held[i][rb].z += kj.z; held[i][rb].w += kj.w;
+                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + 16 * dt + 4 * q) * 4u : OOB, held[i][rb]);
+
                     }
                 }
             }
-            // the next iteration's P1 rewrites the ET images and its P8 the region of the G images
-            __syncthreads();
         }
-        GE2E_PROF(7);
+        GE2E_PROF(6);
+        if (!have_cur) break;
+
+        if (want_grad) {
+            {   // GE's centroid fragments (k-group form): requested here, they land under GC
+                GE2E_T2_LANE();
+                {
+#pragma unroll
+                    for (int i = 0; i < NTI; ++i) {
+                        const int dt = wid + 8 * i;
+                        const bool on = dt < NT;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
+                            ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
+                            ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
+                        }
+                    }
+                }
+            }
+            // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
+            {
+                GE2E_T2_LANE();
+                const int kh = wid >> 2, sl = wid & 3;
+                if (64 * sl < D) {
+                    f32x16 gc[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
+                    asm volatile("s_nop 4" : "+v"(gc[0]), "+v"(gc[1]));   // VALU write -> (asm) MFMA SrcC: see acc_zero4
+                    h8 gf[2][2], ef[2][2][2];     // [set][hi, lo], [set][b][hi, lo]
+#define T2_GC_LOAD(S_)                                                                   \
+    do {                                                                                 \
+        gf[(S_) & 1][0] = frag_tr(Gh, GP, 16 * (S_), 32 * kh, lv_);                     \
+        gf[(S_) & 1][1] = frag_tr(Gl, GP, 16 * (S_), 32 * kh, lv_);                     \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
+            ef[(S_) & 1][b][0] = frag_tr(ETh, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+            ef[(S_) & 1][b][1] = frag_tr(ETl, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+        }                                                                                \
+    } while (0)
+                    T2_GC_LOAD(0);
+#pragma unroll
+                    for (int s = 0; s < RBC; ++s) {
+                        if (CT_GC || s < RBr) {
+                            if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) mfma32x3(gc[b], gf[s & 1][0], gf[s & 1][1], ef[s & 1][b][0], ef[s & 1][b][1]);
+                            __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+                        }
+                    }
+#undef T2_GC_LOAD
+                    T2_SETTLE32(gc[0], gc[1]);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        T2_KEEP(gf[st][0]); T2_KEEP(gf[st][1]);
+                        T2_KEEP(ef[st][0][0]); T2_KEEP(ef[st][0][1]); T2_KEEP(ef[st][1][0]); T2_KEEP(ef[st][1][1]);
+                    }
+                    // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
+                    bool ok = true;
+                    if (seq > 0) {
+                        int okv = 1;
+                        if (lv_ == 0) okv = spin_until(&fl->c3, (unsigned)(N * seq), ctl) ? 1 : 0;
+                        ok = __builtin_amdgcn_readfirstlane(okv) != 0;
+                    }
+                    if (ok) {
+                        // lane (d = l31, h): register i = slot 32 kh + (i & 3) + 8 (i >> 2) + 4 h, column 64 sl + 32 b + l31.
+                        // One dword per lane: every store instruction writes two whole 128-byte row segments (a 16-byte-
+                        // per-lane store of this accumulator would scatter 32-byte pieces over 32 rows, and every piece
+                        // leaves the L2 as a write request of its own)
+                        const int l31 = lv_ & 31, h = lv_ >> 5;
+                        const unsigned ob = XO.gc + (unsigned)((id.member * NC + 32 * kh + 4 * h) * D + 64 * sl + l31) * 4u;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gc[b][i]), rsX,
+                                    ob + (unsigned)(((i & 3) + 8 * (i >> 2)) * D + 32 * b) * 4u, 0, 0);
+                    }
+                }
+            }
+            GE2E_PROF(7);
+        }
+        GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under GE and the next A1
+        if (want_grad) {
+            // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
+            // The G fragments of the next row block and this block's epilogue operands are requested before the MFMAs.
+            {
+                GE2E_T2_LANE();
+                int rbg = RB;
+                asm volatile("" : "+s"(rbg));
+                h8 gb[2][2][2];             // [set][s2][hi, lo]: G rows 16 rb + l15, slots 32 s2 + 8 q ..
+#define T2_GE_LOAD(RB_)                                                                                      \
+    do {                                                                                                     \
+        const int r_ = 16 * (RB_) + l15;                                                                     \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
+            gb[(RB_) & 1][s2][0] = frag_row(Gh + r_ * GP + 32 * s2 + 8 * q);                                 \
+            gb[(RB_) & 1][s2][1] = frag_row(Gl + r_ * GP + 32 * s2 + 8 * q);                                 \
+        }                                                                                                    \
+    } while (0)
+                T2_GE_LOAD(0);
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb) {
+                    if (rb < rbg) {
+                        const int r = 16 * rb + l15;
+                        if (rb > 0) T2_GE_LOAD(rb);
+                        const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
+                        h4 eh[NTI], el[NTI];
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            const int eo = r * P + min(16 * (wid + 8 * i), D - 16) + 4 * q;
+                            eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
+                            el[i] = *reinterpret_cast<const h4*>(ETl + eo);
+                        }
+                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  One tile at a time: chain, settle, epilogue
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            f32x4 acc = acc_zero4();
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2)
+                                mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
+                            T2_SETTLE16_1(acc);
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                T2_KEEP(gb[rb & 1][s2][0]); T2_KEEP(gb[rb & 1][s2][1]); T2_KEEP(ga[i][s2][0]); T2_KEEP(ga[i][s2][1]);
+                            }
+                            held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
+                                                      fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
+                                                      fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
+                                                      fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
+                    }
+                }
+#undef T2_GE_LOAD
+            }
+        }
+        // the next iteration's A rewrites the ET images and the stage inside the X block
+        __syncthreads();
+        GE2E_PROF(8);
     }
-    if (failed) GE2E_TEAM_FAIL();
-    GE2E_PROF_FLUSH(10)
+    if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GE2E_PROF_FLUSH(12)
+#undef GE2E_T2_LOAD_ROWS
+#undef GE2E_T2_LANE
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MR>
-static hipError_t launch_nch(Problem& p, TeamWs& L, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR>);
+template <int NCH, int MR, int RBT, bool CONTRAST>
+static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST>);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
     if (err != hipSuccess) return err;
-    // Every workgroup must be resident (they wait for each other).  That is what a cooperative launch checks --
-    // grid <= resident capacity -- and all it does on this platform; the same check is made here and the kernel
-    // goes out as an ordinary launch (rocprofv3 7.2 crashes at process exit after a cooperative launch, and the
-    // ordinary path is a few microseconds cheaper).  Spins in the kernel are bounded either way.
-    static int resident_per_cu[5][2] = {};
-    int& per_cu = resident_per_cu[NCH][MR == MAXM];
-    if (per_cu == 0) {
-        int nb = 0;
-        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
+    if (p.test_abort) {
+        err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&reinterpret_cast<TeamCtl*>(p.ws)->abort_), 1, 1, stream);
         if (err != hipSuccess) return err;
-        per_cu = nb > 0 ? nb : -1;
     }
+    // Every workgroup must be resident (they wait for each other): grid <= resident capacity is what a cooperative
+    // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
+    // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
+    // behind it redoes every batch with the one-workgroup-per-batch kernel.
+    int nb = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
+    if (err != hipSuccess) return err;
     const int grid = team_grid(p.B);
-    if (per_cu < 0 || grid > per_cu * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    if (nb < 1 || grid > nb * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
     return hipGetLastError();
+}
+template <int NCH, int MR>
+static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
+    if (NCH == 4 && MR == 10 && L.rt == 80)   // the metric shape: compile-time trip counts
+        return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
+    return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
 }
 
 hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem p = p_in;
-    TeamWs L = team_layout(p.N, p.M, p.D);
+    TeamKWs L = team_layout(p.N, p.M, p.D);
+    hipError_t err;
     if (p.M <= 10) {
         switch (p.D / 64) {
-            case 1: return launch_nch<1, 10>(p, L, stream);
-            case 2: return launch_nch<2, 10>(p, L, stream);
-            case 3: return launch_nch<3, 10>(p, L, stream);
-            default: return launch_nch<4, 10>(p, L, stream);
+            case 1: err = launch_variant<1, 10>(p, L, stream); break;
+            case 2: err = launch_variant<2, 10>(p, L, stream); break;
+            case 3: err = launch_variant<3, 10>(p, L, stream); break;
+            default: err = launch_variant<4, 10>(p, L, stream); break;
+        }
+    } else {
+        switch (p.D / 64) {
+            case 1: err = launch_variant<1, 16>(p, L, stream); break;
+            case 2: err = launch_variant<2, 16>(p, L, stream); break;
+            case 3: err = launch_variant<3, 16>(p, L, stream); break;
+            default: err = launch_variant<4, 16>(p, L, stream); break;
         }
     }
-    switch (p.D / 64) {
-        case 1: return launch_nch<1, MAXM>(p, L, stream);
-        case 2: return launch_nch<2, MAXM>(p, L, stream);
-        case 3: return launch_nch<3, MAXM>(p, L, stream);
-        default: return launch_nch<4, MAXM>(p, L, stream);
-    }
+    if (err != hipSuccess) return err;
+    // gated fall-back: runs only if the team kernel raised its abort word (workgroups exit at once otherwise)
+    Problem f = p_in;
+    const TeamCtl* ctl = reinterpret_cast<const TeamCtl*>(p_in.ws);
+    f.gate = &ctl->abort_;
+    f.grid_cap = TEAM_FALLBACK_GRID;
+    f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
+                                    align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange(p.D).stride, 256));
+    return launch_fused_split(f, stream);
 }
 
 }  // namespace ge2e

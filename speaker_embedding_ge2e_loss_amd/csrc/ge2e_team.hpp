@@ -67,7 +67,9 @@ __device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, T
 
 // Called by all threads of the workgroup; `sh` is 4 ints of LDS.  Contains workgroup barriers.
 __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && ld_poll(&ctl->abort_)) {   // launch already marked as failed (diagnostics): nobody forms a team
+        sh[0] = -1; sh[1] = 0; sh[2] = 0;
+    } else if (threadIdx.x == 0) {
         const unsigned x = xcc_id();
         const unsigned ticket = add_agent(&ctl->xcd_count[x][0], 1u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket add has been performed before "arrived" moves
@@ -170,19 +172,5 @@ __device__ __forceinline__ f32x4 gemm_g_ch_tile(const GFrag& g, const _Float16* 
         acc = mfma3_16(g.hi[s], g.lo[s], frag_tr16(CHh, pc, s, cb, lane), frag_tr16(CHl, pc, s, cb, lane), acc);
     return acc;
 }
-
-// ---- GE2E_IMPL_TEAM (ge2e_team.hip) ---------------------------------------------------------------
-struct TeamWs {
-    int spm;            // speakers per member = ceil(N / 8)
-    int rt;             // rows of a member's images: spm * M rounded up to 16
-    size_t chx, cstx, gcx, scx, stride;   // per-team exchange area (offsets / size in floats)
-    size_t head_bytes;  // TeamCtl + TeamFlags[64] at the head of the workspace
-    size_t lds_bytes;
-};
-bool team_supports(int N, int M, int D);
-TeamWs team_layout(int N, int M, int D);
-int team_grid(int B);
-size_t team_workspace_bytes(int B, int N, int M, int D);
-hipError_t launch_team(const Problem& p, hipStream_t stream);
 
 }  // namespace ge2e

@@ -1,13 +1,13 @@
-// GE2E_IMPL_TEAM2 (ge2e_team2.hip): eight workgroups of one XCD share a batch, E is read from HBM once,
+// GE2E_IMPL_TEAM (ge2e_team.hip): eight workgroups of one XCD share a batch, E is read from HBM once,
 // flat 16-row blocks (no padding of a speaker's M rows to an MFMA block).
 #pragma once
 #include "ge2e_common.hpp"
-#include "ge2e_team.hpp"
+#include "ge2e_team.hpp"   // formation + hand-off building blocks
 
 namespace ge2e {
 
 // per-team counters, each on a 128-byte line of its own; zeroed by the memset node in front of the launch
-struct Team2Flags {
+struct TeamKFlags {
     unsigned c1;   unsigned pad0[31];   // hand-off 1: unit centroids of a batch published   (+1 per member)
     unsigned c2;   unsigned pad1[31];   // hand-off 2: partial centroid gradients published  (+1 per member)
     unsigned c3;   unsigned pad2[31];   // partial gradients of a batch have been READ       (+1 per speaker)
@@ -15,7 +15,7 @@ struct Team2Flags {
 
 // Per-team exchange area (byte offsets from the team's base): a function of D alone, so the kernel (templated on D)
 // folds every offset into an immediate instead of keeping a dozen SGPRs live.
-struct Team2X {
+struct TeamKX {
     unsigned chr[2];    // [64 slots][hi D | lo D] halfs      unit centroids * 2^8, row-major          (double-buffered)
     unsigned cht[2];    // [8 members][hi, lo][D][8 slots]    the same, one 16-byte k-group per d       (double-buffered)
     unsigned cst[2];    // [64][4] floats                     1/|c|, kappa, |s|, |s|^2                  (double-buffered)
@@ -23,8 +23,8 @@ struct Team2X {
     unsigned gc;        // [8 members][64 slots][D] floats    partial centroid gradients (single buffer, guarded by c3)
     unsigned stride;    // bytes per team
 };
-constexpr Team2X team2_exchange(int D) {
-    Team2X x{};
+constexpr TeamKX team_exchange(int D) {
+    TeamKX x{};
     unsigned o = 0;
     for (int b = 0; b < 2; ++b) { x.chr[b] = o; o += 64u * 2 * D * 2; }
     for (int b = 0; b < 2; ++b) { x.cht[b] = o; o += 8u * 2 * D * 16; }
@@ -36,21 +36,21 @@ constexpr Team2X team2_exchange(int D) {
     return x;
 }
 
-struct Team2Ws {
+struct TeamKWs {
     int spm;            // speaker slots per member = ceil(N / 8) (<= 8)
     int rt;             // rows of a member's images: spm * M rounded up to 16 (<= 80)
     int mul_m;          // ceil(2^16 / M): r / M = (r * mul_m) >> 16 for r < 2^16 / M
-    unsigned head_bytes;   // TeamCtl + Team2Flags[64]
+    unsigned head_bytes;   // TeamCtl + TeamKFlags[64]
     unsigned xb_bytes, g_bytes;   // LDS regions that are shared by two uses (see the kernel)
     size_t lds_bytes;
 };
 
-constexpr int TEAM2_FALLBACK_GRID = 32;   // workgroups of the gated fall-back launch
+constexpr int TEAM_FALLBACK_GRID = 32;   // workgroups of the gated fall-back launch
 
-bool team2_supports(int N, int M, int D);
-Team2Ws team2_layout(int N, int M, int D);
-int team2_grid(int B);
-size_t team2_workspace_bytes(int B, int N, int M, int D);
-hipError_t launch_team2(const Problem& p, hipStream_t stream);
+bool team_supports(int N, int M, int D);
+TeamKWs team_layout(int N, int M, int D);
+int team_grid(int B);
+size_t team_workspace_bytes(int B, int N, int M, int D);
+hipError_t launch_team(const Problem& p, hipStream_t stream);
 
 }  // namespace ge2e

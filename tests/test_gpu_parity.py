@@ -20,7 +20,6 @@ TOL = {  # impl -> (loss rtol, dE rel-fro / relative max-abs, dw rtol, cos atol)
     "fused_split": (2e-5, 2e-5, 5e-5, 5e-6),
     "tiled": (2e-5, 2e-5, 5e-5, 5e-6),
     "team": (2e-5, 2e-5, 5e-5, 5e-6),
-    "team2": (2e-5, 2e-5, 5e-5, 5e-6),
     "auto": (1e-4, 1e-4, 1e-4, 1e-5),
 }
 
@@ -35,7 +34,7 @@ def GF():
 
 def impls_for(GF, B, N, M, D, variant="softmax"):
     out = []
-    for name in ("generic", "fused_f32", "fused_split", "tiled", "team", "team2"):
+    for name in ("generic", "fused_f32", "fused_split", "tiled", "team"):
         try:
             GF.resolve_impl(B, N, M, D, variant, name)
             out.append(name)

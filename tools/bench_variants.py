@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from speaker_embedding_ge2e_loss_amd import build  # noqa: E402
 
-impl = os.environ.get("IMPL", "team2")
+impl = os.environ.get("IMPL", "team")
 for k, defs in enumerate(sys.argv[1:] or [""]):
     lib = os.path.join(build.PKG_DIR, f"libge2e_hip_exp_v{k}.so")
     build.build_variant(lib, defs.split())

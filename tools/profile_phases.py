@@ -28,7 +28,7 @@ PHASES = {
              "P2 centroid images -> LDS", "P3 X = CH.ET^T (+ dE stores of prev)", "P4 softmax in registers",
              "P5 KJP, gE tiles, scalars + barrier", "P6 G images", "P7 partial gC, rows request, publish, barrier",
              "wait 2 (partial gradients of prev)", "P8(prev) reduce -> KJ, dE complete"],
-    "team2": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
+    "team": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
               "B requests, X, partials requested + barrier", "S softmax, G images + barrier",
               "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "GE + end barrier"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
@@ -81,7 +81,7 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     cyc = prof.cpu().numpy().astype(float) / B
-    if args.impl in ("team", "team2"):
+    if args.impl in ("team", "team"):
         cyc /= 8.0          # eight workgroups stamp every batch; report one workgroup's timeline
     tot = cyc.sum()
     names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])
