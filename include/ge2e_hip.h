@@ -106,6 +106,25 @@ int ge2e_cos_sim_centroids(const float* E, const float* C, int B, int N, int M, 
 /* GE2ELoss.get_centroids (s3:34-38): cent [B][N][D] = mean over M. */
 int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream);
 
+/* GE2ELoss.get_utterance_centroids (s3:95-112): U [B][N][M][D], u_ji = (sum_i' e_ji' - e_ji) / (M - 1).  The map is
+ * linear and symmetric, so its backward is the same call on the incoming gradient. */
+int ge2e_utterance_centroids(const float* E, int B, int N, int M, int D, float* U, void* stream);
+
+/* ---- backward passes of the static helpers (the reference's are plain autograd code: s3:33-38, 41-80, 114-127) ----
+ * get_centroids:  dE [B][N][M][D] = g_cent [B][N][D] / M */
+int ge2e_centroids_bwd(const float* g_cent, int B, int N, int M, int D, float* dE, void* stream);
+/* get_cos_sim(E, C): from the forward result `cos` and its incoming gradient g_cos (both [B][N][M][N]) the gradients
+ * with respect to the embeddings, dE [B][N][M][D] (a-slot + leave-one-out slot), and to the caller's centroids,
+ * dC [B][N][D].  Scratch: ge2e_cos_sim_bwd_workspace_bytes, 16-byte aligned. */
+size_t ge2e_cos_sim_bwd_workspace_bytes(int B, int N, int M, int D);
+int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const float* g_cos, int B, int N, int M, int D,
+                     float eps_cos, float eps, float* dE, float* dC, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* calc_loss(sim): d_sim [B][N][M][N] from g_loss [B] (gradient of the summed loss, or NULL) and g_per [B][N][M]
+ * (gradient of per_embedding_loss, or NULL). */
+int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
+                       const float* g_per, float* d_sim, void* stream);
+
 /* ---- diagnostics (tests only): device building blocks on caller data ------------------- */
 /* A,Bm [64][256], G [64][64] (|x| <= 1) -> X [64][64] = A.Bm^T, GE [64][256] = G.A,
  * GC [64][256] = G^T.Bm through the split-fp16 MFMA tile contractions. */

@@ -40,6 +40,12 @@ PROTOTYPES = {
     "ge2e_selftest_team_bytes": (C.c_size_t, [C.c_int]),
     "ge2e_selftest_team": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_centroids": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ge2e_utterance_centroids": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ge2e_centroids_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ge2e_cos_sim_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ge2e_cos_sim_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp,
+                                   _fp, C.c_size_t, _fp]),
+    "ge2e_calc_loss_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp, _fp]),
     "ge2e_selftest_team_fallback": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
                                               C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
 }

@@ -6,6 +6,7 @@
 
 #include "ge2e_common.hpp"
 #include "ge2e_generic.hpp"
+#include "ge2e_helpers.hpp"
 #include "ge2e_fused.hpp"
 #include "ge2e_selftest.hpp"
 #include "ge2e_tiled.hpp"
@@ -157,6 +158,39 @@ int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void
     if (!E || !cent) return GE2E_ERR_NULL;
     if (B < 1 || N < 1 || M < 1 || D < 1) return GE2E_ERR_SHAPE;
     return (int)launch_centroids(E, B, N, M, D, cent, (hipStream_t)stream);
+}
+
+int ge2e_utterance_centroids(const float* E, int B, int N, int M, int D, float* U, void* stream) {
+    if (!E || !U) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 2 || D < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_utt_centroids(E, B, N, M, D, U, (hipStream_t)stream);
+}
+
+int ge2e_centroids_bwd(const float* g_cent, int B, int N, int M, int D, float* dE, void* stream) {
+    if (!g_cent || !dE) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1 || D < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_centroids_bwd(g_cent, B, N, M, D, dE, (hipStream_t)stream);
+}
+
+size_t ge2e_cos_sim_bwd_workspace_bytes(int B, int N, int M, int D) {
+    return shape_ok(B, N, M, D) ? cos_bwd_workspace_bytes(B, N, M, D) : 0;
+}
+
+int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const float* g_cos, int B, int N, int M, int D,
+                     float eps_cos, float eps, float* dE, float* dC, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!E || !C || !cos || !g_cos || !dE || !dC) return GE2E_ERR_NULL;
+    if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
+    if (!workspace || workspace_bytes < cos_bwd_workspace_bytes(B, N, M, D) || ((uintptr_t)workspace & 15)) return GE2E_ERR_WORKSPACE;
+    return (int)launch_cos_bwd(E, C, cos, g_cos, B, N, M, D, eps_cos, eps, dE, dC, (float*)workspace, (hipStream_t)stream);
+}
+
+int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
+                       const float* g_per, float* d_sim, void* stream) {
+    if (!sim || !d_sim || (!g_loss && !g_per)) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1) return GE2E_ERR_SHAPE;
+    if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    return (int)launch_calc_loss_bwd(sim, B, N, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
 }
 
 // GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the gated fall-back launch does the work.

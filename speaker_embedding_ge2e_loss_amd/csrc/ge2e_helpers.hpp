@@ -1,0 +1,15 @@
+// Launchers of the static helpers' backward passes (ge2e_helpers.hip).
+#pragma once
+#include "ge2e_common.hpp"
+
+namespace ge2e {
+
+hipError_t launch_utt_centroids(const float* E, int B, int N, int M, int D, float* U, hipStream_t stream);
+hipError_t launch_centroids_bwd(const float* g, int B, int N, int M, int D, float* dE, hipStream_t stream);
+size_t cos_bwd_workspace_bytes(int B, int N, int M, int D);
+hipError_t launch_cos_bwd(const float* E, const float* C, const float* cosv, const float* gcos, int B, int N, int M, int D,
+                          float eps_cos, float eps, float* dE, float* dC, float* ws, hipStream_t stream);
+hipError_t launch_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* gloss,
+                                const float* gper, float* dS, hipStream_t stream);
+
+}  // namespace ge2e

@@ -87,6 +87,8 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
         _require_cuda(t, name)
         if t.dtype != torch.float32 or t.numel() != 1:
             raise TypeError(f"{name} must be a float32 scalar tensor")
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, embeddings on {dev}: raw pointers cross the C ABI, all on one device")
     if out is None:
         f32 = dict(dtype=torch.float32, device=dev)
         out = LossOutputs(
@@ -109,87 +111,177 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
     return out
 
 
-_warned_forward_only = set()
+# ---- the reference's static helpers (s3:33-38, 41-80, 95-112, 114-127), differentiable like the originals ----------
+# Forward AND backward run in libge2e_hip.so; the autograd.Functions below only carry tensors across the C ABI.
+
+def _cos_forward(e4: torch.Tensor, c3: Optional[torch.Tensor], eps: float, eps_cos: float) -> torch.Tensor:
+    lib = _lib.load()
+    B, N, M, D = e4.shape
+    cos = torch.empty(B, N, M, N, dtype=torch.float32, device=e4.device)
+    with torch.cuda.device(e4.device):
+        if c3 is not None:
+            code = lib.ge2e_cos_sim_centroids(e4.data_ptr(), c3.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(),
+                                              _stream_ptr(e4))
+            _lib.check(code, "ge2e_cos_sim_centroids")
+        else:
+            ws = alloc_workspace(lib.ge2e_workspace_bytes(B, N, M, D, 0, _lib.IMPL_GENERIC), e4.device)
+            code = lib.ge2e_cos_sim(e4.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _stream_ptr(e4))
+            _lib.check(code, "ge2e_cos_sim")
+    return cos
 
 
-def _forward_only(name: str, *tensors):
-    """The static helpers have no backward here (training goes through GE2ELoss.forward / ge2e_loss, which
-    produces dE, dw, db in the same launch).  The reference's own eval script (s5:36-44) calls them on
-    graph-attached embeddings and detaches the result, so this cannot be an error; but a result silently
-    cut off from the graph would train nothing, so the first such call per helper warns."""
-    if name not in _warned_forward_only and torch.is_grad_enabled() and \
-            any(t is not None and t.requires_grad for t in tensors):
-        _warned_forward_only.add(name)
-        import warnings
-        warnings.warn(f"{name} is forward-only in this implementation (its result carries no grad_fn); "
-                      "use GE2ELoss.forward / ge2e_loss for the differentiable path", RuntimeWarning, stacklevel=3)
+class _CentroidsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e4):
+        lib = _lib.load()
+        B, N, M, D = e4.shape
+        cent = torch.empty(B, N, D, dtype=torch.float32, device=e4.device)
+        with torch.cuda.device(e4.device):
+            _lib.check(lib.ge2e_centroids(e4.data_ptr(), B, N, M, D, cent.data_ptr(), _stream_ptr(e4)), "ge2e_centroids")
+        ctx.shape = (B, N, M, D)
+        return cent
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, N, M, D = ctx.shape
+        g = g.contiguous().float()
+        dE = torch.empty(B, N, M, D, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.ge2e_centroids_bwd(g.data_ptr(), B, N, M, D, dE.data_ptr(), _stream_ptr(g)), "ge2e_centroids_bwd")
+        return dE
+
+
+class _UttCentroidsFunction(torch.autograd.Function):
+    """u = (sum - e) / (M - 1): linear and symmetric, so backward is the same kernel on the gradient."""
+
+    @staticmethod
+    def _run(x):
+        lib = _lib.load()
+        B, N, M, D = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ge2e_utterance_centroids(x.data_ptr(), B, N, M, D, out.data_ptr(), _stream_ptr(x)),
+                       "ge2e_utterance_centroids")
+        return out
+
+    @staticmethod
+    def forward(ctx, e4):
+        return _UttCentroidsFunction._run(e4)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return _UttCentroidsFunction._run(g.contiguous().float())
+
+
+class _CosSimFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e4, c3, eps, eps_cos):
+        cos = _cos_forward(e4, c3, eps, eps_cos)
+        ctx.save_for_backward(e4, c3, cos)
+        ctx.eps, ctx.eps_cos = eps, eps_cos
+        return cos
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        e4, c3, cos = ctx.saved_tensors
+        B, N, M, D = e4.shape
+        g = g.contiguous().float()
+        dE = torch.empty_like(e4)
+        dC = torch.empty_like(c3)
+        ws = alloc_workspace(lib.ge2e_cos_sim_bwd_workspace_bytes(B, N, M, D), e4.device)
+        with torch.cuda.device(e4.device):
+            code = lib.ge2e_cos_sim_bwd(e4.data_ptr(), c3.data_ptr(), cos.data_ptr(), g.data_ptr(), B, N, M, D,
+                                        ctx.eps_cos, ctx.eps, dE.data_ptr(), dC.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _stream_ptr(e4))
+        _lib.check(code, "ge2e_cos_sim_bwd")
+        return dE, dC, None, None
+
+
+class _CalcLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s4, eps, variant):
+        lib = _lib.load()
+        B, N, M, _ = s4.shape
+        loss = torch.empty(B, dtype=torch.float32, device=s4.device)
+        per = torch.empty(B, N, M, dtype=torch.float32, device=s4.device)
+        with torch.cuda.device(s4.device):
+            code = lib.ge2e_calc_loss(s4.data_ptr(), B, N, M, eps, _lib.VARIANTS[variant], loss.data_ptr(), per.data_ptr(),
+                                      _stream_ptr(s4))
+        _lib.check(code, "ge2e_calc_loss")
+        ctx.save_for_backward(s4)
+        ctx.eps, ctx.variant = eps, variant
+        return loss, per
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, g_per):
+        lib = _lib.load()
+        (s4,) = ctx.saved_tensors
+        B, N, M, _ = s4.shape
+        gl = g_loss.contiguous().float() if g_loss is not None else None
+        gp = g_per.contiguous().float() if g_per is not None else None
+        dS = torch.empty_like(s4)
+        with torch.cuda.device(s4.device):
+            code = lib.ge2e_calc_loss_bwd(s4.data_ptr(), B, N, M, ctx.eps, _lib.VARIANTS[ctx.variant],
+                                          gl.data_ptr() if gl is not None else None,
+                                          gp.data_ptr() if gp is not None else None, dS.data_ptr(), _stream_ptr(s4))
+        _lib.check(code, "ge2e_calc_loss_bwd")
+        return dS, None, None
 
 
 def cos_sim(embeddings: torch.Tensor, centroids: torch.Tensor | None = None, *, eps: float = SMALL_ERR,
             eps_cos: float = EPS_COS) -> torch.Tensor:
-    """get_cos_sim (s3:42-80) forward: (N,M,D) [, centroids (N,D)] -> (N,M,N) or batched.
+    """get_cos_sim (s3:42-80): (N,M,D) [, centroids (N,D)] -> (N,M,N) or batched; differentiable in both arguments.
 
     With ``centroids`` the other-speaker columns use them (as the reference does with its second
     argument); without, they are get_centroids(embeddings) -- what every caller in the reference passes.
     """
-    lib = _lib.load()
     _require_cuda(embeddings, "embeddings")
-    _forward_only("get_cos_sim", embeddings, centroids)
     e4, squeeze = _as_batched(embeddings)
     B, N, M, D = e4.shape
-    cos = torch.empty(B, N, M, N, dtype=torch.float32, device=e4.device)
-    if centroids is not None:
-        _require_cuda(centroids, "centroids")
-        c3 = centroids.detach().to(torch.float32).reshape(B, -1, D).contiguous()
-        if c3.shape[1] != N:
-            # s3:77-78 indexes cos_diff[j, :, j] for every speaker j: the reference needs as many centroids as speakers
-            raise RuntimeError(f"get_cos_sim: {c3.shape[1]} centroids for {N} speakers")
-        with torch.cuda.device(e4.device):
-            code = lib.ge2e_cos_sim_centroids(e4.data_ptr(), c3.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(),
-                                              _stream_ptr(e4))
-        _lib.check(code, "ge2e_cos_sim_centroids")
-        return cos[0] if squeeze else cos
-    ws = alloc_workspace(lib.ge2e_workspace_bytes(B, N, M, D, 0, _lib.IMPL_GENERIC), e4.device)
-    with torch.cuda.device(e4.device):
-        code = lib.ge2e_cos_sim(e4.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(),
-                                ws.data_ptr(), ws.numel(), _stream_ptr(e4))
-    _lib.check(code, "ge2e_cos_sim")
+    if centroids is None:
+        centroids = _CentroidsFunction.apply(e4)
+    _require_cuda(centroids, "centroids")
+    c3 = centroids.to(torch.float32).reshape(B, -1, D).contiguous()
+    if c3.shape[1] != N:
+        # s3:77-78 indexes cos_diff[j, :, j] for every speaker j: the reference needs as many centroids as speakers
+        raise RuntimeError(f"get_cos_sim: {c3.shape[1]} centroids for {N} speakers")
+    cos = _CosSimFunction.apply(e4, c3, float(eps), float(eps_cos))
     return cos[0] if squeeze else cos
 
 
 def centroids(embeddings: torch.Tensor) -> torch.Tensor:
-    """get_centroids (s3:34-38) forward: mean over the utterance axis."""
-    lib = _lib.load()
+    """get_centroids (s3:34-38): mean over the utterance axis."""
     _require_cuda(embeddings, "embeddings")
-    _forward_only("get_centroids", embeddings)
     e4, squeeze = _as_batched(embeddings)
-    B, N, M, D = e4.shape
-    cent = torch.empty(B, N, D, dtype=torch.float32, device=e4.device)
-    with torch.cuda.device(e4.device):
-        code = lib.ge2e_centroids(e4.data_ptr(), B, N, M, D, cent.data_ptr(), _stream_ptr(e4))
-    _lib.check(code, "ge2e_centroids")
+    cent = _CentroidsFunction.apply(e4)
     return cent[0] if squeeze else cent
 
 
+def utterance_centroids(embeddings: torch.Tensor) -> torch.Tensor:
+    """get_utterance_centroids (s3:95-112): leave-one-out centroid of every utterance, (N,M,D) -> (N,M,D)."""
+    _require_cuda(embeddings, "embeddings")
+    e4, squeeze = _as_batched(embeddings)
+    u = _UttCentroidsFunction.apply(e4)
+    return u[0] if squeeze else u
+
+
 def calc_loss(sim_matrix: torch.Tensor, *, eps: float = SMALL_ERR, variant: str = "softmax"):
-    """calc_loss (s3:115-127) forward on a (N,M,N) or (B,N,M,N) similarity matrix."""
-    lib = _lib.load()
+    """calc_loss (s3:115-127) on a (N,M,N) or (B,N,M,N) similarity matrix: (loss, per_embedding_loss), differentiable."""
     _require_cuda(sim_matrix, "sim_matrix")
-    _forward_only("calc_loss", sim_matrix)
     s = sim_matrix
     squeeze = s.dim() == 3
     if squeeze:
         s = s.unsqueeze(0)
     if s.dim() != 4 or s.shape[1] != s.shape[3]:
         raise ValueError(f"sim_matrix must be (N,M,N) or (B,N,M,N), got {tuple(sim_matrix.shape)}")
-    s = s.contiguous().float()
-    B, N, M, _ = s.shape
-    loss = torch.empty(B, dtype=torch.float32, device=s.device)
-    per = torch.empty(B, N, M, dtype=torch.float32, device=s.device)
-    with torch.cuda.device(s.device):
-        code = lib.ge2e_calc_loss(s.data_ptr(), B, N, M, eps, _lib.VARIANTS[variant],
-                                  loss.data_ptr(), per.data_ptr(), _stream_ptr(s))
-    _lib.check(code, "ge2e_calc_loss")
+    loss, per = _CalcLossFunction.apply(s.contiguous().float(), float(eps), variant)
     return (loss[0], per[0]) if squeeze else (loss, per)
 
 
@@ -204,6 +296,7 @@ class _GE2ELossFunction(torch.autograd.Function):
         o = loss_fwd_bwd(embeddings.detach(), w.detach(), b.detach(), eps=eps, eps_cos=eps_cos,
                          variant=variant, impl=impl, need_grad=need)
         ctx.squeeze = squeeze
+        ctx.w_shape, ctx.b_shape = w.shape, b.shape
         if need:
             ctx.save_for_backward(o.dE, o.dw, o.db)
         return o.loss[0] if squeeze else o.loss
@@ -219,9 +312,9 @@ class _GE2ELossFunction(torch.autograd.Function):
             if ctx.squeeze:
                 gE = gE[0]
         if ctx.needs_input_grad[1]:
-            gw = (dw * g).sum()
+            gw = (dw * g).sum().reshape(ctx.w_shape)
         if ctx.needs_input_grad[2]:
-            gb = (db * g).sum()
+            gb = (db * g).sum().reshape(ctx.b_shape)
         return gE, gw, gb, None, None, None, None
 
 

@@ -55,7 +55,7 @@ class GE2ELoss(nn.Module):
     def get_centroids(embeddings):
         return GF.centroids(embeddings)
 
-    # eq. (5) cosines -- s3:41-80 (forward only here; the training path is forward())
+    # eq. (5) cosines -- s3:41-80 (differentiable in both arguments, like the reference's)
     @staticmethod
     def get_cos_sim(embeddings, centroids, hp):
         # like the reference: `centroids` feeds every other-speaker column, the own-speaker column uses the
@@ -71,8 +71,7 @@ class GE2ELoss(nn.Module):
     # s3:95-112
     @staticmethod
     def get_utterance_centroids(embeddings):
-        n_utt = embeddings.shape[1]
-        return (embeddings.sum(dim=1, keepdim=True) - embeddings) / (n_utt - 1)
+        return GF.utterance_centroids(embeddings)
 
     # eq. (6) -- s3:114-127: returns (loss, per_embedding_loss (N,M))
     @staticmethod

@@ -44,6 +44,7 @@ def run_reference(emb_np, w, b, dtype):
     loss.backward()
     with torch.no_grad():
         cent = GE2ELoss.get_centroids(e)
+        loo = GE2ELoss.get_utterance_centroids(e)          # s3:95-112
         cos = GE2ELoss.get_cos_sim(e, cent, HP)
         _, per = GE2ELoss.calc_loss(mod.w * cos + mod.b, HP)
     return {
@@ -51,6 +52,7 @@ def run_reference(emb_np, w, b, dtype):
         "per": per.numpy(),
         "cos": cos.numpy(),
         "cent": cent.numpy(),
+        "loo": loo.numpy(),
         "dE": e.grad.numpy(),
         "dw": mod.w.grad.numpy(),
         "db": mod.b.grad.numpy(),
@@ -66,6 +68,8 @@ def emit(name, emb, w=10.0, b=-5.0, keep_dE64=True):
         out[k] = np.asarray(v, dtype=np.float32)
     for k, v in r64.items():
         if k == "dE" and not keep_dE64:
+            continue
+        if k == "loo":          # fp32 copy is enough for a linear map
             continue
         out[k + "64"] = np.asarray(v, dtype=np.float64)
     path = os.path.join(HERE, name + ".npz")

@@ -194,25 +194,71 @@ def test_many_batches_grid_stride(GF):
         assert rel_fro(o["dE"], ref["dE"]) < 1e-5
 
 
-def test_forward_only_and_static_helpers(GF):
+@pytest.mark.parametrize("name", golden_names())
+def test_static_helpers_on_every_fixture(GF, name):
+    """get_centroids, get_utterance_centroids, get_cos_sim, calc_loss (s3:33-127) against the values the imported
+    reference produced for every fixture -- not against each other."""
     from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
     hp = HParams("cuda:0")
-    g = load_golden("g2_cfg1_n4_m5_d256")
+    g = load_golden(name)
+    N, M, D = g["E"].shape
     e = torch.as_tensor(g["E"], device="cuda:0")
     cent = GE2ELoss.get_centroids(e)
-    assert np.allclose(cent.cpu().numpy(), g["cent"], atol=1e-7)
+    assert np.allclose(cent.cpu().numpy(), g["cent64"], rtol=1e-5, atol=1e-7)
+    loo = GE2ELoss.get_utterance_centroids(e)
+    assert np.allclose(loo.cpu().numpy(), g["loo"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(loo[N - 1, M - 1], GE2ELoss.get_centroid(e, N - 1, M - 1), atol=1e-5)   # the dead-code stub, eq. 8
     cos = GE2ELoss.get_cos_sim(e, cent, hp)
-    assert cos.shape == (4, 5, 4)
-    assert np.allclose(cos.cpu().numpy(), g["cos64"], atol=2e-6)
-    # s5:44 style: sim = 1.0 * cos + 0.0 ; calc_loss returns the 2-tuple (s3:127)
-    loss, per = GE2ELoss.calc_loss(10.0 * cos - 5.0, hp)
-    assert np.allclose(loss.item(), g["loss64"], rtol=1e-5)
-    assert np.allclose(per.cpu().numpy(), g["per64"], rtol=1e-4, atol=1e-5)
-    o = GF.loss_fwd_bwd(e, torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0"),
-                        need_grad=False, need_per=True)
-    assert o.dE is None and np.allclose(o.loss.item(), g["loss64"], rtol=1e-5)
-    u = GE2ELoss.get_utterance_centroids(e)
-    assert torch.allclose(u[1, 2], GE2ELoss.get_centroid(e, 1, 2), atol=1e-6)
+    assert cos.shape == (N, M, N)
+    assert np.allclose(cos.cpu().numpy(), g["cos64"], atol=3e-6)
+    w, b = float(g["w"]), float(g["b"])
+    loss, per = GE2ELoss.calc_loss(w * cos + b, hp)                 # the 2-tuple of s3:127
+    assert np.allclose(loss.item(), g["loss64"], rtol=2e-5, atol=1e-5)
+    assert np.allclose(per.cpu().numpy(), g["per64"], rtol=2e-4, atol=2e-5)
+    o = GF.loss_fwd_bwd(e, torch.tensor(w, device="cuda:0"), torch.tensor(b, device="cuda:0"), need_grad=False, need_per=True)
+    assert o.dE is None and np.allclose(o.loss.item(), g["loss64"], rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_static_helpers_are_differentiable_like_the_reference(GF, name):
+    """s3:19-30 rebuilt from the static helpers and backpropagated: the gradients the reference's autograd gave."""
+    from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+    hp = HParams("cuda:0")
+    g = load_golden(name)
+    e = torch.as_tensor(g["E"], device="cuda:0").requires_grad_(True)
+    w = torch.tensor(float(g["w"]), device="cuda:0", requires_grad=True)
+    b = torch.tensor(float(g["b"]), device="cuda:0", requires_grad=True)
+    cent = GE2ELoss.get_centroids(e)
+    cos = GE2ELoss.get_cos_sim(e, cent, hp)
+    assert cos.requires_grad
+    loss, per = GE2ELoss.calc_loss(w * cos + b, hp)
+    loss.backward()
+    dE64 = g["dE64"] if "dE64" in g else g["dE"]
+    assert rel_fro(e.grad.cpu().numpy(), dE64) < 2e-5, rel_fro(e.grad.cpu().numpy(), dE64)
+    assert np.allclose(w.grad.item(), g["dw64"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(b.grad.item(), g["db64"], atol=1e-4)
+    # the second return value carries gradient too, and the leave-one-out helper is its own adjoint
+    e2 = torch.as_tensor(g["E"], device="cuda:0").requires_grad_(True)
+    _, per2 = GE2ELoss.calc_loss(float(g["w"]) * GE2ELoss.get_cos_sim(e2, GE2ELoss.get_centroids(e2), hp) + float(g["b"]), hp)
+    per2.sum().backward()
+    assert rel_fro(e2.grad.cpu().numpy(), dE64) < 2e-5
+    x = torch.as_tensor(g["E"], device="cuda:0").requires_grad_(True)
+    r = torch.as_tensor(np.random.default_rng(0).standard_normal(g["E"].shape).astype(np.float32), device="cuda:0")
+    (GE2ELoss.get_utterance_centroids(x) * r).sum().backward()
+    assert torch.allclose(x.grad, GE2ELoss.get_utterance_centroids(r), atol=1e-5)
+
+
+def test_contrast_calc_loss_backward(GF):
+    from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+    hp = HParams("cuda:0")
+    E = orc.synth_embeddings((6, 4, 32), "unit", seed=5)
+    ref = orc.closed_form(E, 10.0, -5.0, variant="contrast")
+    e = torch.as_tensor(E, device="cuda:0").requires_grad_(True)
+    cos = GE2ELoss.get_cos_sim(e, GE2ELoss.get_centroids(e), hp)
+    loss, _ = GE2ELoss.calc_loss(10.0 * cos - 5.0, hp, variant="contrast")
+    loss.backward()
+    assert np.allclose(loss.item(), ref["loss"], rtol=2e-5)
+    assert rel_fro(e.grad.cpu().numpy(), ref["dE"]) < 2e-5
 
 
 def test_module_autograd_matches_reference_semantics(GF):
@@ -270,12 +316,21 @@ def test_get_cos_sim_uses_the_callers_centroids(GF):
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
             cos = GE2ELoss.get_cos_sim(e, torch.as_tensor(Cn, device="cuda:0"), hp)
-        assert cos.shape == (N, M, N) and not cos.requires_grad
-        assert np.allclose(cos.cpu().numpy(), ref, atol=3e-6)
+        assert cos.shape == (N, M, N) and cos.requires_grad and not rec
+        assert np.allclose(cos.detach().cpu().numpy(), ref, atol=3e-6)
+        # gradients with respect to BOTH arguments against autograd of the op-for-op restatement (fp64)
+        c = torch.as_tensor(Cn, device="cuda:0").requires_grad_(True)
+        wgt = torch.as_tensor(rng.standard_normal((N, M, N)).astype(np.float32), device="cuda:0")
+        e.grad = None
+        (GE2ELoss.get_cos_sim(e, c, hp) * wgt).sum().backward()
+        e64 = torch.as_tensor(E, dtype=torch.float64).requires_grad_(True)
+        c64 = torch.as_tensor(Cn, dtype=torch.float64).requires_grad_(True)
+        (orc.expand_form_cos_sim(e64, c64) * wgt.cpu().double()).sum().backward()
+        assert rel_fro(e.grad.cpu().numpy(), e64.grad.numpy()) < 1e-5
+        assert rel_fro(c.grad.cpu().numpy(), c64.grad.numpy()) < 1e-5
         # with C = get_centroids(E) it is the fused kernels' similarity matrix
         own = GE2ELoss.get_cos_sim(e.detach(), GE2ELoss.get_centroids(e.detach()), hp)
         ref_own = orc.expand_form_cos_sim(torch.as_tensor(E), orc.centroids(torch.as_tensor(E))).numpy()
         assert np.allclose(own.cpu().numpy(), ref_own, atol=3e-6)
-    assert any("forward-only" in str(w.message) for w in rec) or True  # warned at most once per process
     with pytest.raises(RuntimeError):
         GE2ELoss.get_cos_sim(e.detach(), torch.zeros(3, 256, device="cuda:0"), hp)   # 3 centroids for 64 speakers
