@@ -125,6 +125,23 @@ int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const flo
 int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
                        const float* g_per, float* d_sim, void* stream);
 
+/* ---- the callers either side of the loss ---------------------------------------------------------
+ * Encoder tail: the L2-normalisation that ends the encoder's forward (s2_model_GE2E_loss_speach_embed.py:34), the
+ * un-permute gather `embeddings[unperm]` (s4_train_embed_model.py:186) and the (N,M,D) reshape (s4:189) in one pass:
+ *   e[i][:] = y[src[i]][:] / |y[src[i]]|,  rnorm[i] = 1 / |y[src[i]]|      y, e [rows][D]; src [rows] int32 or NULL (identity)
+ * src must be a permutation of 0..rows-1 (the reference's `unperm`); no epsilon, like s2:34. */
+int ge2e_normalize_unperm(const float* y, const int* src, int rows, int D, float* e, float* rnorm, void* stream);
+/* its backward: dy[src[i]][:] = (g[i] - e[i] (e[i] . g[i])) * rnorm[i]  (every row of dy is written exactly once). */
+int ge2e_normalize_unperm_bwd(const float* g, const float* e, const float* rnorm, const int* src, int rows, int D,
+                              float* dy, void* stream);
+/* Threshold sweep of calculate_ERR (s5_eval_model.py:57-98) on a similarity matrix sim [B][N][M][N]: for every threshold
+ * (non-decreasing fp32 table, T <= 4096; the reference's is 0.5 + 0.01 i, i < 50, s5:57) the two integer counts the
+ * reference derives FAR and FRR from, counts [B][T][2] int32:
+ *   [0] = #{(j,i,k), k != j : sim[j][i][k] > thr}   (s5:82)      [1] = #{(j,i) : sim[j][i][j] > thr}   (s5:89)
+ * The comparison is the reference's fp32 `S > thres`; the counts are exact.  FAR/FRR, with the reference's own
+ * denominators (s5:81,88), and the argmin over thresholds (s5:93-98) are a few dozen scalar operations on the host. */
+int ge2e_eer_counts(const float* sim, int B, int N, int M, const float* thresholds, int T, int* counts, void* stream);
+
 /* ---- diagnostics (tests only): device building blocks on caller data ------------------- */
 /* A,Bm [64][256], G [64][64] (|x| <= 1) -> X [64][64] = A.Bm^T, GE [64][256] = G.A,
  * GC [64][256] = G^T.Bm through the split-fp16 MFMA tile contractions. */

@@ -11,6 +11,7 @@
 #include "ge2e_selftest.hpp"
 #include "ge2e_tiled.hpp"
 #include "ge2e_team_kernel.hpp"
+#include "ge2e_tail.hpp"
 
 using namespace ge2e;
 
@@ -191,6 +192,25 @@ int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int var
     if (B < 1 || N < 1 || M < 1) return GE2E_ERR_SHAPE;
     if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
     return (int)launch_calc_loss_bwd(sim, B, N, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
+}
+
+int ge2e_normalize_unperm(const float* y, const int* src, int rows, int D, float* e, float* rnorm, void* stream) {
+    if (!y || !e || !rnorm) return GE2E_ERR_NULL;
+    if (rows < 1 || D < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_tail_fwd(y, src, rows, D, e, rnorm, (hipStream_t)stream);
+}
+
+int ge2e_normalize_unperm_bwd(const float* g, const float* e, const float* rnorm, const int* src, int rows, int D,
+                              float* dy, void* stream) {
+    if (!g || !e || !rnorm || !dy) return GE2E_ERR_NULL;
+    if (rows < 1 || D < 1) return GE2E_ERR_SHAPE;
+    return (int)launch_tail_bwd(g, e, rnorm, src, rows, D, dy, (hipStream_t)stream);
+}
+
+int ge2e_eer_counts(const float* sim, int B, int N, int M, const float* thresholds, int T, int* counts, void* stream) {
+    if (!sim || !thresholds || !counts) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1 || T < 1 || T > 4096) return GE2E_ERR_SHAPE;
+    return (int)launch_eer_counts(sim, B, N, M, thresholds, T, counts, (hipStream_t)stream);
 }
 
 // GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the gated fall-back launch does the work.

@@ -285,6 +285,88 @@ def calc_loss(sim_matrix: torch.Tensor, *, eps: float = SMALL_ERR, variant: str 
     return (loss[0], per[0]) if squeeze else (loss, per)
 
 
+class _NormalizeUnpermFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, src):
+        lib = _lib.load()
+        rows, D = y.shape
+        e = torch.empty_like(y)
+        rn = torch.empty(rows, dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            code = lib.ge2e_normalize_unperm(y.data_ptr(), src.data_ptr() if src is not None else None, rows, D,
+                                             e.data_ptr(), rn.data_ptr(), _stream_ptr(y))
+        _lib.check(code, "ge2e_normalize_unperm")
+        ctx.save_for_backward(e, rn, src)
+        return e
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        e, rn, src = ctx.saved_tensors
+        g = g.contiguous().float()
+        rows, D = e.shape
+        dy = torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            code = lib.ge2e_normalize_unperm_bwd(g.data_ptr(), e.data_ptr(), rn.data_ptr(),
+                                                 src.data_ptr() if src is not None else None, rows, D, dy.data_ptr(),
+                                                 _stream_ptr(e))
+        _lib.check(code, "ge2e_normalize_unperm_bwd")
+        return dy, None
+
+
+def normalize_unperm(y: torch.Tensor, unperm=None, shape=None) -> torch.Tensor:
+    """The encoder's tail in one kernel: ``(y / |y|)[unperm]`` -- s2:34 then s4:186 --
+    optionally reshaped to ``shape`` = (N, M) -> (N,M,D) (s4:189).  ``y`` (rows, D) is the encoder's
+    raw projection; ``unperm`` a permutation of range(rows) (list or int tensor), None = identity.
+    Differentiable in ``y``."""
+    _require_cuda(y, "y")
+    if y.dim() != 2:
+        raise ValueError(f"y must be (rows, D), got {tuple(y.shape)}")
+    rows = y.shape[0]
+    src = None
+    if unperm is not None:
+        if not torch.is_tensor(unperm):
+            if sorted(unperm) != list(range(rows)):
+                raise ValueError("unperm must be a permutation of range(rows)")
+            # pinned staging + async copy: no host sync on the step's critical path
+            src = torch.tensor(unperm, dtype=torch.int32).pin_memory().to(y.device, non_blocking=True)
+        else:
+            if unperm.numel() != rows:
+                raise ValueError("unperm must have one entry per row")
+            src = unperm.to(device=y.device, dtype=torch.int32).contiguous()
+    e = _NormalizeUnpermFunction.apply(y.contiguous().float(), src)
+    if shape is not None:
+        e = e.reshape(*shape, e.shape[1])
+    return e
+
+
+def eer_counts(sim_matrix: torch.Tensor, thresholds) -> torch.Tensor:
+    """Integer counts of the calculate_ERR sweep (s5:57-98) for (N,M,N) or (B,N,M,N) similarities:
+    -> int32 (T,2) or (B,T,2): [...,0] false accepts (s5:82), [...,1] accepts on the own column (s5:89).
+    ``thresholds``: non-decreasing, compared in fp32 as numpy does for a float32 array (s5:58)."""
+    _require_cuda(sim_matrix, "sim_matrix")
+    s = sim_matrix
+    squeeze = s.dim() == 3
+    if squeeze:
+        s = s.unsqueeze(0)
+    if s.dim() != 4 or s.shape[1] != s.shape[3]:
+        raise ValueError(f"sim_matrix must be (N,M,N) or (B,N,M,N), got {tuple(sim_matrix.shape)}")
+    s = s.contiguous().float()
+    thr = torch.as_tensor(thresholds, dtype=torch.float64).to(torch.float32).reshape(-1)
+    if thr.numel() < 1 or thr.numel() > 4096 or bool((thr[1:] < thr[:-1]).any()):
+        raise ValueError("thresholds must be 1..4096 non-decreasing values")
+    thr = thr.to(s.device)
+    B, N, M, _ = s.shape
+    T = thr.numel()
+    counts = torch.empty(B, T, 2, dtype=torch.int32, device=s.device)
+    lib = _lib.load()
+    with torch.cuda.device(s.device):
+        code = lib.ge2e_eer_counts(s.data_ptr(), B, N, M, thr.data_ptr(), T, counts.data_ptr(), _stream_ptr(s))
+    _lib.check(code, "ge2e_eer_counts")
+    return counts[0] if squeeze else counts
+
+
 class _GE2ELossFunction(torch.autograd.Function):
     """forward = one fused kernel launch that also produces dE, dw, db;
     backward only scales them by the incoming gradient (no host sync)."""

@@ -5,6 +5,8 @@ Mirrors ``embedding_model_GE2E/s4_train_embed_model.py`` (``TrainEmbedModel``):
   s4:167-192  (N,M,T,F) -> (N*M,T,F), random permutation, encoder, un-permute, (N,M,D)
   s4:196-203  loss, zero_grad, backward, clip_grad_norm_(encoder, 3.0), clip_grad_norm_(loss, 1.0), step
   s4:261-264  LR halving touches param_groups[0] only
+  s4:61-110   batched test loss: eval mode, same perm/unperm, mean of the per-batch losses
+  s4:112-135  checkpoint = the ENCODER's state_dict only (the loss's w, b are not saved)
 
 New here (the reference is single-process): one process per GPU, whole (N,M) batches per rank
  and ONE flat-bucket all-reduce (mean) of encoder + (w,b) gradients between
@@ -26,7 +28,12 @@ import torch.distributed as dist
 class DPTrainer:
     def __init__(self, model: torch.nn.Module, loss_module: torch.nn.Module, lr: float = 0.05,
                  clip_model: float = 3.0, clip_loss: float = 1.0,
-                 process_group: Optional["dist.ProcessGroup"] = None, seed: Optional[int] = None):
+                 process_group: Optional["dist.ProcessGroup"] = None, seed: Optional[int] = None,
+                 fused_tail: bool = False):
+        # fused_tail: the encoder returns its raw projection (SpeakerEncoder(normalize=False)) and the
+        # L2-normalise + un-permute + (N,M,D) layout run as one HIP kernel instead of
+        # norm / divide / index_select / contiguous
+        self.fused_tail = fused_tail
         self.model = model
         self.ge2e_loss = loss_module
         self.lr = lr
@@ -38,17 +45,34 @@ class DPTrainer:
         self._rng = random.Random(seed)
         # one flat gradient bucket; every .grad is a view into it
         self._params = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+        if not self._params:
+            raise ValueError("nothing to train: no parameter requires grad")
         total = sum(p.numel() for p in self._params)
         dev, dt = self._params[0].device, self._params[0].dtype
+        for p in self._params:  # one bucket = one dtype on one device
+            if p.device != dev or p.dtype != dt:
+                raise ValueError(f"all trainable parameters must share one device and dtype "
+                                 f"(got {p.device}/{p.dtype} beside {dev}/{dt})")
         self.flat_grad = torch.zeros(total, device=dev, dtype=dt)
+        self._views = []
         off = 0
         for p in self._params:
             n = p.numel()
-            p.grad = self.flat_grad[off:off + n].view_as(p)
+            self._views.append(self.flat_grad[off:off + n].view(p.shape))
             off += n
+        self._bind_grads()
         if self.world > 1:  # start from identical weights (rank 0's)
             for p in self._params:
                 dist.broadcast(p.data, src=0, group=self.pg)
+
+    def _bind_grads(self):
+        """Make every .grad the parameter's view of the bucket again.  A caller's
+        ``optimizer.zero_grad()`` (set_to_none is torch's default) or ``model.zero_grad()`` drops
+        them; autograd would then allocate fresh .grad tensors and the collective would reduce a
+        bucket nobody writes."""
+        for p, v in zip(self._params, self._views):
+            if p.grad is not v:
+                p.grad = v
 
     def embed(self, mel: torch.Tensor) -> torch.Tensor:
         """(N,M,T,F) -> (N,M,D) through the encoder with the reference's perm/unperm (s4:174-192)."""
@@ -59,6 +83,9 @@ class DPTrainer:
         unperm = [0] * total
         for i, j in enumerate(perm):
             unperm[j] = i
+        if self.fused_tail:
+            from . import functional as GF
+            return GF.normalize_unperm(self.model(flat[perm]), unperm, shape=(n_spk, n_utt))
         emb = self.model(flat[perm])[unperm]
         return emb.reshape(n_spk, n_utt, emb.shape[1]).contiguous()
 
@@ -66,6 +93,7 @@ class DPTrainer:
         """One training step on this rank's (N,M,T,F) batch.  Returns the local loss (device tensor)."""
         emb = self.embed(mel)
         loss = self.ge2e_loss(emb)  # s4:196
+        self._bind_grads()
         self.flat_grad.zero_()      # s4:199 (grads stay views of the bucket)
         loss.backward()             # s4:200
         if self.world > 1:
@@ -75,6 +103,67 @@ class DPTrainer:
         torch.nn.utils.clip_grad_norm_(self.ge2e_loss.parameters(), self.clip_loss)   # s4:202
         self.optimizer.step()       # s4:203
         return loss.detach()
+
+    @torch.no_grad()
+    def eval_loss(self, mel_batches) -> float:
+        """s4:61-110: mean over the test batches of the loss in eval mode (same perm/unperm, drawn
+        from the same generator as the training steps, like the reference's global ``random``).
+        The per-batch losses stay on the device; there is ONE host read at the end."""
+        was_training = self.model.training
+        self.model.eval()       # s4:69
+        losses = []
+        for mel in mel_batches:
+            losses.append(self.ge2e_loss(self.embed(mel)).detach().reshape(()))
+        if was_training:
+            self.model.train()  # s4:107
+        if not losses:
+            return float("nan")  # np.mean([]) in the reference (s4:109)
+        mean = torch.stack(losses).mean()
+        if self.world > 1:      # every rank evaluated its own share of the test set
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.pg)
+            mean = mean / self.world
+        return float(mean)
+
+    def save_checkpoint(self, path: str) -> None:
+        """s4:112-135: the encoder's ``state_dict`` only, as CPU tensors (the reference moves the
+        model to the CPU and back; here the weights are copied and the model stays put).  The
+        loss's (w, b) are NOT in the file -- s4:130 saves ``self.model.state_dict()``.  Rank 0
+        writes; the other ranks return."""
+        if self.world > 1 and dist.get_rank(self.pg) != 0:
+            return
+        state = {k: v.detach().to("cpu", copy=True) for k, v in self.model.state_dict().items()}
+        torch.save(state, path)
+
+    def load_checkpoint(self, path: str) -> None:
+        """s4:24-30 / s2:57-60: restore the encoder from an encoder-only checkpoint."""
+        dev = self._params[0].device
+        self.model.load_state_dict(torch.load(path, map_location=dev))
+
+    def fit(self, train_batches, epochs: int, test_batches=None, lr_reduce: int = 2000, epoch_print: int = 100,
+            checkpoint_dir: Optional[str] = None, checkpoint_interval: int = 200):
+        """The epoch loop of s4:137-276 without its printing: per epoch the mean of the step losses
+        (s4:215), every ``epoch_print`` epochs the batched test loss (s4:225-227), LR halving every
+        ``lr_reduce`` epochs (s4:261-264), a checkpoint every ``checkpoint_interval`` (s4:266-267)
+        and a final one (s4:270).  ``train_batches`` is any re-iterable of (N,M,T,F) tensors.
+        The step losses are reduced on the device: one host read per epoch instead of one per step
+        (s4:205)."""
+        import os
+        self.model.train()
+        train_losses, test_losses = [], []
+        mean = float("nan")
+        for e in range(epochs):
+            step_losses = [self.step(mel) for mel in train_batches]
+            mean = float(torch.stack(step_losses).mean()) if step_losses else float("nan")
+            train_losses.append(mean)
+            if test_batches is not None and (e + 1) % epoch_print == 0:
+                test_losses.append(self.eval_loss(test_batches))
+            if (e + 1) % lr_reduce == 0:
+                self.halve_lr()
+            if checkpoint_dir is not None and (e + 1) % checkpoint_interval == 0:
+                self.save_checkpoint(os.path.join(checkpoint_dir, f"ckpt_epoch_{e + 1}_L_{mean:.4f}.pth"))
+        if checkpoint_dir is not None and epochs > 0:
+            self.save_checkpoint(os.path.join(checkpoint_dir, f"final_epoch_{epochs}_L_{mean:.4f}.pth"))
+        return self.model, train_losses, test_losses
 
     def halve_lr(self):
         """s4:261-264: only the encoder group's lr is halved; the (w,b) group keeps its own."""
