@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """GE2E loss+backward throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--impl auto]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--impl auto] [--mode loss|train-step]
 
-One *step* = one launch of the hot path (ge2e_loss_fwd_bwd through the C ABI) over B
-independent synthetic (N,M,D) batches that are already resident in HBM.  The metric is
-(N x M) batches per second; with --gpus N>1 (launched by torch.distributed.run, one rank
-per GPU) every rank processes its own B batches (weak scaling, no data-path collective;
-the only reduction is loss/dw/db) and the value is the whole-job aggregate
-over the max-over-ranks time.  Rank 0 prints ONE JSON line.
+--mode loss (default).  One *step* = one launch of the hot path (ge2e_loss_fwd_bwd through the C ABI)
+over B independent synthetic (N,M,D) batches that are already resident in HBM.  The metric is (N x M)
+batches per second.  With --gpus N>1 every rank processes its own B batches (weak scaling, no
+data-path collective; the only reduction is loss/dw/db) and the value is the whole-job
+aggregate over the max-over-ranks time.
+
+--mode train-step.  The data-parallel step of s4:193-203 around the loss: per step one loss launch on this
+rank's batches, (dw, db) into the tail of the flat gradient bucket, ONE SUM all-reduce of the
+1,464,578-float bucket (the reference encoder's 1,464,576 parameters + w + b, trainer.py's layout) on
+the nccl (= RCCL) backend, and the division by the world size.  Timed with the collective (the value)
+and again without it (train_step.ms_without_allreduce).  The encoder's own forward/backward is library
+work outside this path and is not in the step.
+
+Ranks: launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the environment) the script is
+one rank.  Run as plain `python bench.py --gpus N` with N>1 it starts that launcher itself as a child
+process -- before anything in this process touches the GPU -- and exits with the child's code.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,15 +37,41 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {  # BASELINE.json "configs"; cfg2 is the one the metric is quoted on
     "cfg1": dict(N=4, M=5, D=256, variant="softmax", B=16384),
-    # B = batches per launch, resident in HBM (2.7 GB of E at cfg2): 16 batches per workgroup amortise the launch ramp,
-    # the first batch's un-overlapped sweep 1 and the tail (measured: 1.45 M/s at B=1024, 1.57 at 2048, 1.66 at 4096,
-    # 1.69 at 8192)
+    # B = batches per launch, resident in HBM (2.7 GB of E at cfg2): amortises the launch ramp, the first batch's
+    # un-overlapped load and the tail
     "cfg2": dict(N=64, M=10, D=256, variant="softmax", B=4096),
     "cfg3": dict(N=64, M=10, D=256, variant="contrast", B=4096),
     "cfg4": dict(N=256, M=10, D=256, variant="softmax", B=256),
     "cfg5": dict(N=1024, M=10, D=768, variant="softmax", B=16),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (no sparsity)
+BUCKET_FLOATS = 1464578    # LSTM(80->256, 3 layers) + Linear(256,256) + w + b  (s2:13-25, s3:16-17)
+SPLIT_IMPLS = ("fused_split", "team", "tiled")
+ARITH = {
+    True: "split-fp16x3 MFMA (hi.hi + hi.lo + lo.hi, 2^8 prescale, ~22 mantissa bits), fp32 accumulate; "
+          "norms, softmax and reductions in fp32",
+    False: "fp32 FMA throughout",
+}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD (never exec-replace), wait, pass its
+    exit code on.  Nothing in this process has touched the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def synth(B, N, M, D, seed, device):
@@ -89,20 +127,31 @@ def cpu_baseline(N, M, D, variant, budget_s=12.0):
 
 
 def measured_traffic(cfg_name, impl, B):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
-    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, see tools/summarize_rocprof.py).  The counters cannot be
-    read from inside this process; the figure is reported only for the exact (config, impl, B) it
-    was measured on, otherwise null."""
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/run_profiles.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  The counters cannot be read from inside this
+    process.  The record carries the hash of the kernel sources it was measured on; it is reported only for the exact
+    (config, impl, B) AND only while that hash still matches the tree -- otherwise null."""
     try:
+        from speaker_embedding_ge2e_loss_amd.build import source_hash
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             table = json.load(f)
-        for key in (cfg_name, f"{cfg_name}_{impl}"):
-            t = table.get(key)
-            if t and t["impl"] == impl and t["batches_per_launch"] == B:
-                return t["fetch_bytes"] + t["write_bytes"]
+        t = table.get(f"{cfg_name}_{impl}")
+        if t and t["impl"] == impl and t["batches_per_launch"] == B and t.get("source_hash") == source_hash():
+            return t["fetch_bytes"] + t["write_bytes"]
     except Exception:
         pass
     return None
+
+
+def time_launches(fn, steps):
+    """HIP events on the stream the kernels are launched on (torch's current stream) -> per-step ms."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
 def main():
@@ -112,122 +161,257 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
     ap.add_argument("--impl", default="auto")
-    ap.add_argument("--batches", type=int, default=0, help="B per launch per GPU (0 = config default)")
+    ap.add_argument("--mode", default="loss", choices=["loss", "train-step"])
+    ap.add_argument("--batches", type=int, default=0,
+                    help="B per launch per GPU (0 = config default; train-step default 1 = one (N,M) batch per rank per step, as s4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the B=1 latency legs and the exact-fp32 comparison (profiling runs: only the benched kernel)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: ranks, rendezvous (gloo), the bucket all-reduce and the JSON line only; value is null")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    if not torch.cuda.is_available():
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "train-step":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from speaker_embedding_ge2e_loss_amd import functional as GF
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = dict(CONFIGS[args.config])
     N, M, D, variant = cfg["N"], cfg["M"], cfg["D"], cfg["variant"]
-    B = args.batches or cfg["B"]
-    impl = GF.resolve_impl(B, N, M, D, variant, args.impl)
+    B = args.batches or (1 if args.mode == "train-step" else cfg["B"])
 
-    E = synth(B, N, M, D, 1234 + rank, dev)
-    w = torch.tensor(10.0, device=dev)
-    b = torch.tensor(-5.0, device=dev)
-    out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None,
-                         dE=torch.empty_like(E), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
-    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, variant, impl), dev)
+    if dry:
+        impl = args.impl
 
-    def step():
-        GF.loss_fwd_bwd(E, w, b, variant=variant, impl=impl, out=out, workspace=ws)
+        def step():
+            pass
+    else:
+        from speaker_embedding_ge2e_loss_amd import functional as GF
+        impl = GF.resolve_impl(B, N, M, D, variant, args.impl)
+        E = synth(B, N, M, D, 1234 + rank, dev)
+        w = torch.tensor(10.0, device=dev)
+        b = torch.tensor(-5.0, device=dev)
+        out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None,
+                             dE=torch.empty_like(E), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
+        ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, variant, impl), dev)
+
+        def step():
+            GF.loss_fwd_bwd(E, w, b, variant=variant, impl=impl, out=out, workspace=ws)
+
+    bucket = None
+    if args.mode == "train-step":
+        bucket = torch.zeros(BUCKET_FLOATS, device=dev)
+        # the encoder's gradient: random stand-in, resident (its backward is library work outside this path)
+        bucket[:-2] = torch.randn(BUCKET_FLOATS - 2, generator=torch.Generator().manual_seed(99 + rank)).to(dev) * 1e-3
+        loss_step = step
+
+        def tail():
+            if not dry:
+                bucket[-2:] = torch.stack([out.dw.sum(), out.db.sum()])  # s4:200: (w, b) grads land in the bucket
+
+        def step_with():
+            loss_step()
+            tail()
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)   # trainer.py: one message per step
+            bucket.div_(world)
+
+        def step_without():
+            loss_step()
+            tail()
+            bucket.div_(world)
+
+        step = step_with
+
+    def barrier():
+        sync()
+        if dist and world > 1:
+            dist.barrier()
+        sync()
+
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        ms = time_launches(fn, steps) if not dry else [0.0] * steps
+        if dry:
+            for _ in range(steps):
+                fn()
+        barrier()
+        return time.perf_counter() - t0, ms
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the stream the kernel is launched on (torch's current stream)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        step()
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    launch_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    elapsed, launch_ms = timed(step, args.steps)
 
-    # the only cross-rank reduction of the loss-only job: loss / dw / db sums
-    red = torch.stack([out.loss.sum(), out.dw.sum(), out.db.sum(),
-                       torch.tensor(elapsed, device=dev, dtype=torch.float32)])
     tmax = elapsed
-    if dist:
+    loss_mean = None
+    if dist and world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
-        dist.all_reduce(red[:3], op=dist.ReduceOp.SUM)
-    loss_mean = float(red[0].item()) / (B * world)
+    if not dry:
+        # the only cross-rank reduction of the loss-only job: loss / dw / db sums
+        red = torch.stack([out.loss.sum(), out.dw.sum(), out.db.sum()])
+        if dist and world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        loss_mean = float(red[0].item()) / (B * world)
 
-    # B = 1 latency (not the metric; reported for honesty about launch-bound single batches)
-    lat_us = None
-    if rank == 0:
+    train = None
+    if args.mode == "train-step":
+        for _ in range(max(2, args.warmup // 2)):
+            step_without()
+        el_wo, _ = timed(step_without, args.steps)
+        # the collective alone, back to back
+        for _ in range(3):
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        el_ar, _ = timed(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM), args.steps)
+        tt = torch.tensor([el_wo, el_ar], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el_wo, el_ar = float(tt[0]), float(tt[1])
+        nbytes = BUCKET_FLOATS * 4
+        train = {"bucket_floats": BUCKET_FLOATS, "bucket_bytes": nbytes,
+                 "backend": "gloo (dry run)" if dry else "nccl (RCCL)",
+                 "ms_with_allreduce": tmax / args.steps * 1e3,
+                 "ms_without_allreduce": el_wo / args.steps * 1e3,
+                 "allreduce_alone_ms": el_ar / args.steps * 1e3,
+                 # ring all-reduce moves 2 (n-1)/n of the message over every link
+                 "allreduce_busbw_GBs": (2 * (world - 1) / world * nbytes / (el_ar / args.steps) / 1e9) if world > 1 else None}
+
+    extra = {}
+    if rank == 0 and not dry and args.mode == "loss" and not args.no_extras:
+        # B = 1 latency, raw C-ABI call (not the metric; launch-bound single batches)
         e1 = E[:1].contiguous()
         o1 = GF.LossOutputs(loss=out.loss[:1], per=None, dE=out.dE[:1], dw=out.dw[:1], db=out.db[:1])
         impl1 = GF.resolve_impl(1, N, M, D, variant, args.impl)
         ws1 = GF.alloc_workspace(GF.workspace_bytes(1, N, M, D, variant, impl1), dev)
+        call1 = lambda: GF.loss_fwd_bwd(e1, w, b, variant=variant, impl=impl1, out=o1, workspace=ws1)  # noqa: E731
         for _ in range(5):
-            GF.loss_fwd_bwd(e1, w, b, variant=variant, impl=impl1, out=o1, workspace=ws1)
-        torch.cuda.synchronize()
-        s, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(20):
-            GF.loss_fwd_bwd(e1, w, b, variant=variant, impl=impl1, out=o1, workspace=ws1)
-        e_.record()
-        torch.cuda.synchronize()
-        lat_us = s.elapsed_time(e_) / 20 * 1e3
+            call1()
+        extra["latency_b1_us"] = float(np.mean(time_launches(call1, 20))) * 1e3
+        extra["latency_b1_impl"] = impl1
+
+        # what a user of the reference's class pays per training step at B=1: GE2ELoss.forward + loss.backward()
+        # through the module (allocator, autograd, the grad_out scaling), s4:193-200
+        from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+        mod = GE2ELoss(HParams(device=dev), variant=variant, impl=args.impl)
+        em = E[0].clone().requires_grad_(True)
+
+        def module_step():
+            em.grad = None
+            mod.zero_grad(set_to_none=True)
+            mod(em).backward()
+
+        for _ in range(5):
+            module_step()
+        extra["latency_module_b1_us"] = float(np.mean(time_launches(module_step, 20))) * 1e3
+
+        # the exact-fp32 kernel beside the split-fp16 one (same workload; fewer steps)
+        if impl in SPLIT_IMPLS and world == 1:
+            for cand in ("fused_f32", "generic"):
+                try:
+                    if GF.resolve_impl(B, N, M, D, variant, cand) != cand:
+                        continue
+                    wsx = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, variant, cand), dev)
+                    callx = lambda: GF.loss_fwd_bwd(E, w, b, variant=variant, impl=cand, out=out, workspace=wsx)  # noqa: E731
+                    callx()
+                    torch.cuda.synchronize()
+                    msx = float(np.mean(time_launches(callx, max(3, min(10, args.steps)))))
+                    extra["exact_f32"] = {"impl": cand, "value": B / (msx * 1e-3), "unit": "batches/s",
+                                          "ms_per_launch": msx, "arith": ARITH[False]}
+                    step()  # leave the outputs as the benched implementation wrote them
+                    torch.cuda.synchronize()
+                    break
+                except Exception as ex:  # unsupported shape for this kernel
+                    extra["exact_f32"] = {"impl": cand, "value": None, "note": str(ex)[:120]}
 
     if rank == 0:
         total_batches = B * args.steps * world
-        value = total_batches / tmax
+        value = None if dry else total_batches / tmax
         bytes_per_batch = 2 * N * M * D * 4  # read E once + write dE once
-        flops_per_batch = 6 * N * N * M * D
-        avg_launch_s = float(np.mean(launch_ms)) * 1e-3
-        achieved = bytes_per_batch * B / avg_launch_s / 1e9
+        flops_per_batch = 6 * N * N * M * D  # three N x (N M) x D contractions, 2 flops per MAC
+        split = impl in SPLIT_IMPLS
+        roof = None
+        if not dry:
+            avg_launch_s = float(np.mean(launch_ms)) * 1e-3
+            alg_tf = flops_per_batch * B / avg_launch_s / 1e12
+            alg_gbs = bytes_per_batch * B / avg_launch_s / 1e9
+            # which roof binds: arithmetic intensity of the shape against the machine balance of the
+            # arithmetic actually issued (3 MFMA per product in split form)
+            issued_tf = alg_tf * (3 if split else 1)
+            mfma_bound = split and (issued_tf / MFMA_F16_PEAK_TF) > (alg_gbs / HBM_PEAK_GBS)
+            common = {"kernel": f"ge2e {impl}", "avg_launch_ms": avg_launch_s * 1e3,
+                      "algorithmic_bytes_per_launch": bytes_per_batch * B,
+                      "algorithmic_flops_per_launch": flops_per_batch * B,
+                      "achieved_algorithmic_tflops": alg_tf, "achieved_algorithmic_GBs": alg_gbs,
+                      "hbm_frac": alg_gbs / HBM_PEAK_GBS,
+                      "mfma_frac": issued_tf / MFMA_F16_PEAK_TF if split else None}
+            if args.mode == "train-step":
+                common["note"] = "launch time here includes the bucket all-reduce (train-step mode)"
+            if mfma_bound:
+                roof = {"bound": "mfma", "achieved": issued_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": issued_tf / MFMA_F16_PEAK_TF, "traffic": measured_traffic(args.config, impl, B),
+                        "achieved_is": "issued f16 MFMA flops = 3 x algorithmic (split-fp16x3)", **common}
+            else:
+                roof = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, impl, B), **common}
+        name = {"loss": "GE2E loss+backward throughput", "train-step": "GE2E data-parallel train-step throughput "
+                "(loss+backward + flat-bucket grad all-reduce)"}[args.mode]
         line = {
-            "metric": "GE2E loss+backward throughput, (spk x utt) batches/sec at N=64 M=10 D=256"
-                      if args.config == "cfg2" else f"GE2E loss+backward throughput, batches/sec ({args.config})",
+            "metric": f"{name}, (spk x utt) batches/sec at N={N} M={M} D={D}",
             "value": value, "unit": "batches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "arith": ARITH[impl in SPLIT_IMPLS] if not dry else None,
+            "data": "synthetic" if not dry else "dry-run (no kernel launched)",
             "config": {"workload": f"{args.config}: N={N} M={M} D={D} {variant} GE2E fwd+bwd, "
-                                   f"B={B} batches per launch per GPU, w=10 b=-5",
-                       "N": N, "M": M, "D": D, "variant": variant, "batches_per_launch": B,
-                       "impl": impl, "parallelism": f"dp{world} (independent batches, no data-path collective)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, impl, B),
-                         "kernel": f"ge2e {impl}", "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": bytes_per_batch * B,
-                         "algorithmic_flops_per_launch": flops_per_batch * B,
-                         "achieved_tflops": flops_per_batch * B / avg_launch_s / 1e12},
-            "latency_b1_us": lat_us,
+                                   f"B={B} batches per launch per GPU, w=10 b=-5"
+                                   + (f", + SUM all-reduce of {BUCKET_FLOATS} fp32 grads per step" if train else ""),
+                       "mode": args.mode, "N": N, "M": M, "D": D, "variant": variant, "batches_per_launch": B,
+                       "impl": impl,
+                       "parallelism": f"dp{world} (whole batches per rank" +
+                                      (", one flat-bucket all-reduce per step)" if train else ", no data-path collective)")},
+            "roofline": roof,
             "loss_mean": loss_mean,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if variant == "contrast":
+            line["parity"] = ("unpinned: the reference has no contrast variant (s3 implements softmax only); checked "
+                              "against the fp64 closed-form oracle and finite differences only")
+        line.update(extra)
+        if train:
+            line["train_step"] = train
+        if dry:
+            line["dry_run"] = True
+        if world == 1 and not args.no_cpu_baseline and not dry and args.mode == "loss":
             line["cpu_baseline"] = cpu_baseline(N, M, D, variant)
         print(json.dumps(line), flush=True)
     if dist:
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -30,6 +30,19 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources, headers and per-source flags: identifies the code a profile was taken on
+    (profiles/traffic.json carries it; bench.py reports measured traffic only while it still matches)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

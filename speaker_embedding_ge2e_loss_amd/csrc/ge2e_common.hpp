@@ -173,4 +173,14 @@ __device__ __forceinline__ void unit_stats(float sq, float eps_cos, float& rn, f
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Compute units of the CURRENT device, asked on every call (no per-process cache: a process may drive several devices,
+// and a partitioned MI355X shows fewer).  Without a visible device (build host) size queries answer for a whole MI355X.
+inline int device_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;
+}
+
 }  // namespace ge2e

@@ -31,9 +31,6 @@
 #include "ge2e_fused.hpp"
 #include "ge2e_split_gemm.hpp"
 
-#ifndef GE2E_EXP
-#define GE2E_EXP 0   // bit mask of timing experiments (tools/exp_traffic.py); 0 in every shipped build
-#endif
 namespace ge2e {
 
 namespace {
@@ -172,21 +169,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     bool have_sums = false;   // speaker sums of the current batch already sit in the workspace
     for (int bi = blockIdx.x; bi < p.B; bi += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
-#if GE2E_EXP & 8   // timing experiment only: sweep 2 reads ONE batch's rows
-        const __amdgpu_buffer_rsrc_t rsE2s = make_rsrc(p.E, (unsigned)NM * ROWB);
-#else
         const __amdgpu_buffer_rsrc_t rsE2s = rsE;
-#endif
-#if GE2E_EXP & 2   // timing experiment only (wrong results): sweep 3 re-reads ONE batch's rows, L2-resident
-        const __amdgpu_buffer_rsrc_t rsE3 = make_rsrc(p.E, (unsigned)NM * ROWB);
-#else
         const __amdgpu_buffer_rsrc_t rsE3 = rsE;
-#endif
-#if GE2E_EXP & 4   // timing experiment only: every workgroup writes batch 0's dE
-        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE : nullptr,
-#else
         const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
-#endif
                                                       want_grad ? (unsigned)NM * ROWB : 0u);
 
         // ================= sweep 1: speaker sums -> unit centroid images =====================
@@ -549,11 +534,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         // the next batch of this workgroup: its rows are summed per speaker underneath this sweep
         const int bnext = bi + gridDim.x;
         const bool has_next = bnext < p.B;
-#if GE2E_EXP & 1   // timing experiment only: the next batch's sums are taken from batch 0's rows
-        const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E,
-#else
         const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E + (size_t)(has_next ? bnext : bi) * NM * D,
-#endif
                                                        has_next ? (unsigned)NM * ROWB : 0u);
         const int nr2 = has_next ? nr_w : 0;
         const unsigned base2 = (unsigned)(jb * M) * ROWB;
@@ -666,10 +647,11 @@ FusedWs fused_split_layout(int N, int M, int D) {
     return L;
 }
 
-#ifndef GE2E_SPLIT_GRID
-#define GE2E_SPLIT_GRID 256   // one workgroup per CU (tools/exp_cache_policy.py --grid: fewer did not pay)
-#endif
-int fused_split_grid(int B) { return B < GE2E_SPLIT_GRID ? B : GE2E_SPLIT_GRID; }
+// one persistent workgroup per CU of the current device (fewer did not pay: profiles/r01, grid experiment)
+int fused_split_grid(int B) {
+    const int cus = device_cu_count();
+    return B < cus ? B : cus;
+}
 
 size_t fused_split_workspace_bytes(int B, int N, int M, int D) {
     return (size_t)fused_split_grid(B) * fused_split_layout(N, M, D).stride * sizeof(float);

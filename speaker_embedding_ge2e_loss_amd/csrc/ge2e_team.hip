@@ -167,13 +167,7 @@ __device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned targ
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-static int team_cu_count() {   // queried on every call (no per-process cache: the current device may change)
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        return n;
-    return 256;                // no device visible (build host): size queries answer for a whole MI355X
-}
+static int team_cu_count() { return device_cu_count(); }
 
 TeamKWs team_layout(int N, int M, int D) {
     TeamKWs L{};

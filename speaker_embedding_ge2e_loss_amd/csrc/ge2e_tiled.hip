@@ -755,8 +755,7 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const unsigned row_blocks = (unsigned)(((size_t)p.B * NM + 3) / 4);
     typedef GemmCfg<128, 128> C1;
     typedef GemmCfg<256, 256> C2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    {   // every launch, like the fused kernels: the attribute is per device and a process may drive several
         const void* small[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), reinterpret_cast<const void*>(ge2e_tiled_gc<C1>),
                                reinterpret_cast<const void*>(ge2e_tiled_ge<C1>)};
         const void* big[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), reinterpret_cast<const void*>(ge2e_tiled_gc<C2>),
@@ -769,7 +768,6 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2::LDS_BYTES);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
     }
     auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
     // the 256 x 256 tile where both extents of the contraction's output reach it AND its grid still gives every CU

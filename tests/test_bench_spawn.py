@@ -1,0 +1,41 @@
+"""`python bench.py --gpus N` outside a launcher must start N ranks itself (as a child process, before any GPU call) and
+rank 0 must print one JSON line with n_gpus = N.  Device-less dry run: gloo rendezvous on 127.0.0.1, the real
+1,464,578-float flat-bucket all-reduce of --mode train-step on CPU tensors, no kernel launched (value is null)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=240, env=env, cwd="/tmp")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE json line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_train_step():
+    j = run("--gpus", "2", "--mode", "train-step", "--config", "cfg4")
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["value"] is None
+    assert j["config"]["N"] == 256 and j["config"]["mode"] == "train-step" and j["config"]["batches_per_launch"] == 1
+    t = j["train_step"]
+    assert t["bucket_floats"] == 1464578 and t["bucket_bytes"] == 4 * 1464578
+    assert t["ms_with_allreduce"] > t["ms_without_allreduce"] >= 0 and t["allreduce_alone_ms"] > 0
+    assert "dp2" in j["config"]["parallelism"]
+
+
+def test_gpus_1_stays_one_process():
+    j = run("--gpus", "1")
+    assert j["n_gpus"] == 1 and j["config"]["batches_per_launch"] == 4096 and j["config"]["mode"] == "loss"
+
+
+def test_bucket_is_the_reference_encoder_plus_w_b():
+    from speaker_embedding_ge2e_loss_amd.encoder import SpeakerEncoder
+    enc = SpeakerEncoder()  # 80 mels, 256 hidden, 3 layers, 256-d embedding: strings/constants.py:52,90-92
+    assert sum(p.numel() for p in enc.parameters()) + 2 == 1464578

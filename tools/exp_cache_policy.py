@@ -54,9 +54,5 @@ def run(defs, B=4096, iters=8):
 
 
 if __name__ == "__main__":
-    if "--grid" in sys.argv:   # fewer workgroups in flight = smaller working set in the Infinity Cache, fewer CUs busy
-        for g in (256, 240, 224, 192, 160, 128):
-            run({"GE2E_SPLIT_GRID": g})
-        sys.exit(0)
     for e1, e2, e3, de in [(0, 0, 2, 2), (2, 0, 2, 2), (0, 2, 2, 2), (2, 2, 2, 2), (0, 0, 0, 2), (0, 0, 2, 0), (16, 16, 2, 2)]:
         run({"GE2E_AUX_E1": e1, "GE2E_AUX_E2": e2, "GE2E_AUX_E3": e3, "GE2E_AUX_DE": de})
