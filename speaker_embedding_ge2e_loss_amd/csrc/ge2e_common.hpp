@@ -48,8 +48,11 @@ struct Problem {
         prof_last = prof_now;                                          \
         __builtin_amdgcn_sched_barrier(0);                             \
     } while (0)
+#ifndef GE2E_PROF_TID
+#define GE2E_PROF_TID 0   /* whose view: the first lane of wave GE2E_PROF_TID / 64 */
+#endif
 #define GE2E_PROF_FLUSH(n)                                             \
-    if (threadIdx.x == 0 && p.prof)                                    \
+    if (threadIdx.x == GE2E_PROF_TID && p.prof)                                    \
         for (int prof_i = 0; prof_i < n; ++prof_i) atomicAdd(p.prof + prof_i, prof_acc[prof_i]);
 #else
 #define GE2E_PROF_DECL(n)

@@ -49,6 +49,12 @@ constexpr int AUX_NT = 2;
 #ifndef GE2E_T2_DE_AUX
 #define GE2E_T2_DE_AUX 2      // cache policy of the dE stores (tools/bench_variants.py sweeps it)
 #endif
+#ifndef GE2E_T2_STAGGER_MOD
+#define GE2E_T2_STAGGER_MOD 0
+#endif
+// column tile i of this wave in GE / dE.  Two tiles per wave (D > 128): ADJACENT tiles, so that after the half-row
+// exchange at the end of GE a lane pair-of-tiles covers whole 128-byte lines of dE (see T2_PAIR_LINES)
+#define T2_DT(i) (NTI == 2 ? 2 * wid + (i) : wid + 8 * (i))
 #ifndef GE2E_T2_E_AUX
 #define GE2E_T2_E_AUX 2       // ... and of the E loads
 #endif
@@ -107,22 +113,16 @@ __device__ __forceinline__ void put_split4(_Float16* hi_img, _Float16* lo_img, i
     *reinterpret_cast<h4*>(lo_img + off) = lo;
 }
 
-// MFMAs as inline asm with the accumulator TIED to the destination.  With the builtins hipcc is free to give a chain
-//   v[12:15] = A.B + 0 ;  v[8:11] = A.B' + v[12:15] ;  ds_read_b128 v[12:15], ...   (next fragment into the dead SrcC)
-// and on gfx950 the matrix pipe reads SrcC pass by pass: when the pipe is shared with the SIMD's other wave the MFMA
-// can start late, the LDS read lands first, and the rows of the LAST pass (accumulator lanes 48..63) pick up the new
-// fragment bits instead of the partial sum.  Found with per-thread checksums of two identical launches: every input of
-// GE identical, `held` different in lanes q = 3 only, in 5-75 % of the launches depending on how long the phase ran.
-// A tied accumulator is only ever written by the (in-order) matrix pipe.  Each accumulator's MFMAs are issued BACK TO
-// BACK: with a second, independent chain interleaved (distance 2 between dependent MFMAs) whole 16 x 16 tiles came out
-// wrong whenever the SIMD's other wave was not issuing MFMAs of the same kind at the same time (first / last row block
-// of GE); hipcc would have padded that case with wait states, asm gets none.  hipcc pads nothing around asm, so the wait
-// states between the last MFMA of a chain and the first read of its result are spelled out (T2_SETTLE*).
+// Split-fp16 products on the MFMA builtins.  (An earlier version of this file issued them as inline asm with tied
+// accumulators, hand-placed wait states and operand keep-alives, after wrong 16 x 16 tiles in lanes 48..63 had looked
+// like a SrcC / operand read-after-overwrite race in the matrix pipe.  The cause was elsewhere -- the SLP vectoriser's
+// v_pk_mul_f32 / v_pk_fma_f32 in the fp32 epilogues, see build.py's EXTRA_FLAGS -- and with that flag the builtins pass
+// the 400-launch bitwise-determinism test and every parity case; the scaffolding cost 1 % and is gone.)
 __device__ __forceinline__ void mfma16(f32x4& acc, const h8& a, const h8& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma32(f32x16& acc, const h8& a, const h8& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 // acc += (ah + al) . (bh + bl) without the lo.lo term
 __device__ __forceinline__ void mfma16x3(f32x4& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
@@ -131,28 +131,26 @@ __device__ __forceinline__ void mfma16x3(f32x4& acc, const h8& ah, const h8& al,
 __device__ __forceinline__ void mfma32x3(f32x16& acc, const h8& ah, const h8& al, const h8& bh, const h8& bl) {
     mfma32(acc, ah, bh); mfma32(acc, ah, bl); mfma32(acc, al, bh);
 }
-// ... and the same blindness covers the OPERANDS: hipcc does not know that the asm reads A / B for several cycles after
-// issue (a dependent MFMA starts only when its predecessor's sum is there), so it happily reuses a fragment register
-// for a VALU temporary one instruction later (seen: v_add_u32 v6 right behind `v_mfma .., v[6:9], ..`), and the MFMA
-// multiplies with the temporary.  Every fragment register of a chain is therefore kept live (an empty asm that
-// "reads" it) until the chain's settle has passed.
-#define T2_KEEP(x) asm volatile("" :: "v"(x))
-#define T2_SETTLE16_1(a0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0))
-#define T2_SETTLE16_2(a0, a1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))            /* 16x16x32: 8 passes  */
-#define T2_SETTLE16_4(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
-#define T2_SETTLE32(a0, a1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1))  /* 32x32x16: 16 passes */
-// results of an EARLIER chain may be read once a whole later chain has been issued behind it (the pipe is in order);
-// this empty statement keeps the compiler from moving such a read above the later chain's (volatile) MFMAs
-#define T2_AFTER_1(a0) asm volatile("" : "+v"(a0))
-#define T2_AFTER_2(a0, a1) asm volatile("" : "+v"(a0), "+v"(a1))
-__device__ __forceinline__ f32x4 acc_zero4() {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    // a register, not the inline constant 0: the chain starts in its final home.  hipcc pads nothing around asm, so the
-    // wait states between these VALU writes and an (asm) MFMA reading them as SrcC are spelled out here: without them
-    // whole accumulator tiles started from the register's OLD contents whenever the wave issued back to back
-    asm volatile("s_nop 4" : "+v"(z));
-    return z;
+__device__ __forceinline__ f32x4 acc_zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// dE leaves in WHOLE 128-byte lines.  GE's accumulator layout gives lane (r = l15, q) 16 bytes of row r in each of its
+// two (adjacent) column tiles A and B: one store instruction would write 16 rows x 64 bytes, and half lines cost 29 % more
+// write traffic at the fabric (rocprofv3 WRITE_SIZE 6.09 GB -> 5.30 GB per launch with whole lines, tools/
+// variant_traffic.sh) and 4-8 % of the rate -- the kernel is bound by the write path.  The upper half-row of A and the
+// lower half-row of B change places (DPP row_ror:8 under a bank mask, 3 VALU per dword); afterwards
+//   A: row 8 * 0 + (l15 & 7), B: row 8 + (l15 & 7);  both: columns 16 dtA + 16 (l15 >> 3) + 4 q .. + 3
+// so lanes {l15 & 7 = r} of one instruction write the 128 contiguous bytes of row r.
+__device__ __forceinline__ void pair_lines1(float& a, float& b) {
+    const int ai = __float_as_int(a), bi = __float_as_int(b);
+    // lanes 0..7 of every row of 16 take A[l + 8]; lanes 8..15 keep B
+    const int b2 = __builtin_amdgcn_update_dpp(bi, ai, 0x128, 0xF, 0x3, false);
+    // lanes 8..15 take (old) B[l - 8]; lanes 0..7 keep A
+    const int a2 = __builtin_amdgcn_update_dpp(ai, bi, 0x128, 0xF, 0xC, false);
+    a = __int_as_float(a2);
+    b = __int_as_float(b2);
 }
+#define T2_PAIR_LINES(A_, B_) \
+    do { pair_lines1((A_).x, (B_).x); pair_lines1((A_).y, (B_).y); pair_lines1((A_).z, (B_).z); pair_lines1((A_).w, (B_).w); } while (0)
 
 // one lane waits; the result travels through an LDS word that is not reused for four waits (there is a
 // workgroup barrier between any two of them), so ONE barrier per wait is enough
@@ -178,7 +176,7 @@ TeamKWs team_layout(int N, int M, int D) {
     const int P = D + 16;
     const size_t et = (size_t)2 * L.rt * P * 2;
     size_t xb = (size_t)L.rt * XP * 4;                 // X half-blocks; the first also holds the KJ rows [8][D] of phase F,
-    if (xb < (size_t)8 * D * 4) xb = (size_t)8 * D * 4;   // the second stages the centroid for its k-group form:
+    if (xb < (size_t)16 * D * 4) xb = (size_t)16 * D * 4; // + the member's own slice of its partial gC [8][D]; the second stages the centroid for its k-group form:
     if (xb < (size_t)2 * 8 * (D + STGPAD) * 2) xb = (size_t)2 * 8 * (D + STGPAD) * 2;   // [hi, lo][8 slots][D + 32] halfs
     const size_t g = (size_t)2 * L.rt * GP * 2;        // G images
     L.xb_bytes = (unsigned)xb;
@@ -238,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     float* const RED = CST + NC * 4;                               // [32]
     int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
     float* const KJ = XB0;                                         // F: KJ_j rows [8][D] (X has been consumed by then)
+    float* const OWNP = XB0 + 8 * D;                               // GC -> next A1: own slots of this member's partial gC [8][D]
     _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: centroid stage [hi, lo][8 slots][D + STGPAD]
     constexpr int SP = D + STGPAD;
 
@@ -286,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     float4 rowv[MR];            // this wave's rows of the batch about to start
     float4 held[NTI][RBC];      // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..   (GE -> next iteration)
     float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                      (F -> next F)
+    float4 ownp = zero4();      // this member's own partial gC of this wave's speaker, 4 columns (GC -> LDS -> next F)
     float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
     float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
 #pragma unroll
@@ -312,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const bool dact = d4 < D;                                           \
     (void)l15; (void)q; (void)d4; (void)dact
 
+#ifdef GE2E_T2_STAGGER
+    // teams start out of phase: GE2E_T2_STAGGER x 64 cycles per team index
+    for (int i = 0; i < (GE2E_T2_STAGGER_MOD ? id.team % GE2E_T2_STAGGER_MOD : id.team); ++i) __builtin_amdgcn_s_sleep(GE2E_T2_STAGGER);
+#endif
     GE2E_PROF_DECL(12)
     GE2E_T2_LOAD_ROWS(id.team);
     int wslot = 0;
@@ -324,6 +328,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
                                                        want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
         cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
+        if (have_prev && want_grad) {   // the own slice never travels through L2 (64 KB per batch and team less to write back)
+            GE2E_T2_LANE();
+            ownp = *reinterpret_cast<const float4*>(OWNP + wid * D + min(d4, D - 4));
+        }
 
         // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
         if (have_cur) {
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== B: centroid fragments, previous batch's partial gradients and scalars -> registers ===================
         h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
         h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
-        float4 part[TEAM];
+        float4 part[TEAM - 1];  // the other members' partials of my speaker, in rotated member order (own first, from LDS)
         float4 cstv = zero4(), scv = zero4();
         {
             GE2E_T2_LANE();
@@ -457,13 +465,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                         __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
                     }
                     // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
-                    if (rb > 0) { T2_AFTER_1(acc[(rb & 1) ^ 1]); T2_X_STORE(rb - 1); }
+                    if (rb > 0) { T2_X_STORE(rb - 1); }
                 }
             }
-            T2_SETTLE16_2(acc[0], acc[1]);
-            T2_KEEP(fb[0][0]); T2_KEEP(fb[0][1]); T2_KEEP(fb[1][0]); T2_KEEP(fb[1][1]);
-#pragma unroll
-            for (int s = 0; s < NCH; ++s) { T2_KEEP(xa[s][0]); T2_KEEP(xa[s][1]); }
             if (CT_X) { T2_X_STORE(RBT - 1); }
             else {
 #pragma unroll
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             if (have_prev && want_grad && has_spk) {      // my speaker's eight partial gradients (they land under KJP below)
                 const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
 #pragma unroll
-                for (int m = 0; m < TEAM; ++m)
-                    part[m] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(m * NC + kslot) * ROWB, 0);
+                for (int mm = 1; mm < TEAM; ++mm)
+                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
             }
         }
         if (have_cur && tid == 0) {
@@ -654,9 +658,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 if (!dact) kjp = zero4();
             }
             if (have_prev) {
-                float4 gsum = part[0];
+                // fixed order (own slice first, then members member+1 .. member+7 mod 8): deterministic
+                float4 gsum = ownp;
 #pragma unroll
-                for (int m = 1; m < TEAM; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+                for (int m = 0; m < TEAM - 1; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
                 // every partial of this speaker has been read (the sums above waited for them; nothing of this wave's
                 // is behind them that the counted wait would have to skip): the single gC buffer may be rewritten
                 asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
@@ -673,41 +678,47 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         if (want_grad) __syncthreads();
         GE2E_PROF(5);
 
-        if (want_grad && have_prev) {
-            // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ============
-            // The sums are formed IN the held registers and stored from there: nothing writes those registers again
-            // before the next GE.  A store's data registers must not be reused soon after it: with the memory pipe backed
-            // up (ten 16-byte stores per lane here) a queued store reads its data late, and an LDS read returning into the
-            // same registers meanwhile is not held back -- whole 16 x 16 tiles of the LAST stores of this loop came out
-            // with the next tile's KJ values in 5-20 % of the launches when the sum lived in a reused temporary.
+        // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ================
+        // The sums are formed IN the held registers and stored from there: nothing writes those registers again before
+        // the next GE.  (A store's data registers must not be reused soon after it: with the memory pipe backed up a
+        // queued store reads its data late.)  One row block per step of GC's loop -- the stores' issue slots sit under
+        // its MFMAs instead of forming a phase of their own (stamped: 2.8 k cycles for the older wave of a SIMD, 6 k
+        // for the younger); the last iteration, which has no GC, sends them in one go.
+#define T2_DE_STEP(RB_)                                                                                          \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NTI; ++i_) {                                                     \
+            /* paired tiles hold whole lines (T2_PAIR_LINES): row 8 i + (l15 & 7), columns from the lane's half */ \
+            const int r_ = NTI == 2 ? 16 * (RB_) + 8 * i_ + (l15 & 7) : 16 * (RB_) + l15;                        \
+            const int c_ = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i_) + 4 * q;               \
+            const int loc_ = min((r_ * L.mul_m) >> 16, 7);                                                       \
+            const float4 kj_ = *reinterpret_cast<const float4*>(KJ + loc_ * D + min(c_, D - 4));                 \
+            const bool ok_ = r_ < R_my && T2_DT(i_) < NT;                                                        \
+            held[i_][RB_].x += kj_.x; held[i_][RB_].y += kj_.y; held[i_][RB_].z += kj_.z; held[i_][RB_].w += kj_.w; \
+            bstore4<GE2E_T2_DE_AUX>(rsGp, ok_ ? (unsigned)((j0 * M + r_) * D + c_) * 4u : OOB, held[i_][RB_]);   \
+        }                                                                                                        \
+    } while (0)
+#ifdef GE2E_T2_DE_IN_GC   /* tried: stores under GC's MFMAs -- 7 % slower (the wave blocks at store issue, GC 6 k -> 10 k cycles) */
+        const bool de_in_gc = want_grad && have_prev && have_cur && 64 * (wid & 3) < D;   // this wave runs GC's loop
+#else
+        constexpr bool de_in_gc = false;
+#endif
+        if (want_grad && have_prev && !de_in_gc) {
             GE2E_T2_LANE();
 #pragma unroll
-            for (int i = 0; i < NTI; ++i) {
-                const int dt = wid + 8 * i;
-#pragma unroll
-                for (int rb = 0; rb < RBC; ++rb) {
-                    if (CT_DE || rb < RBr) {
-                        const int r = 16 * rb + l15;
-                        const int loc = min((r * L.mul_m) >> 16, 7);
-                        const float4 kj = *reinterpret_cast<const float4*>(KJ + loc * D + min(16 * dt, D - 16) + 4 * q);
-                        const bool ok = r < R_my && dt < NT;
-                        held[i][rb].x += kj.x; held[i][rb].y += kj.y; held[i][rb].z += kj.z; held[i][rb].w += kj.w;
-                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + 16 * dt + 4 * q) * 4u : OOB, held[i][rb]);
-
-                    }
-                }
-            }
+            for (int rb = 0; rb < RBC; ++rb)
+                if (CT_DE || rb < RBr) T2_DE_STEP(rb);
         }
         GE2E_PROF(6);
         if (!have_cur) break;
 
         if (want_grad) {
+#ifndef GE2E_T2_GA_LATE
             {   // GE's centroid fragments (k-group form): requested here, they land under GC
                 GE2E_T2_LANE();
                 {
 #pragma unroll
                     for (int i = 0; i < NTI; ++i) {
-                        const int dt = wid + 8 * i;
+                        const int dt = T2_DT(i);
                         const bool on = dt < NT;
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) {
@@ -718,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     }
                 }
             }
+#endif
             // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
             {
                 GE2E_T2_LANE();
@@ -728,7 +740,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
-                    asm volatile("s_nop 4" : "+v"(gc[0]), "+v"(gc[1]));   // VALU write -> (asm) MFMA SrcC: see acc_zero4
                     h8 gf[2][2], ef[2][2][2];     // [set][hi, lo], [set][b][hi, lo]
 #define T2_GC_LOAD(S_)                                                                   \
     do {                                                                                 \
@@ -744,18 +755,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     for (int s = 0; s < RBC; ++s) {
                         if (CT_GC || s < RBr) {
                             if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
+                            if (de_in_gc) T2_DE_STEP(s);
 #pragma unroll
                             for (int b = 0; b < 2; ++b) mfma32x3(gc[b], gf[s & 1][0], gf[s & 1][1], ef[s & 1][b][0], ef[s & 1][b][1]);
                             __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
                         }
                     }
 #undef T2_GC_LOAD
-                    T2_SETTLE32(gc[0], gc[1]);
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        T2_KEEP(gf[st][0]); T2_KEEP(gf[st][1]);
-                        T2_KEEP(ef[st][0][0]); T2_KEEP(ef[st][0][1]); T2_KEEP(ef[st][1][0]); T2_KEEP(ef[st][1][1]);
-                    }
+#undef T2_DE_STEP
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -773,15 +780,51 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
 #pragma unroll
-                            for (int i = 0; i < 16; ++i)
+                            for (int i = 0; i < 16; ++i) {
+                                // own slots 8 member .. + 7 = slots 32 kh + 8 (member & 3) + (i & 3) + 4 h stay in LDS (below)
+                                const bool own = kh == (id.member >> 2) && (i >> 2) == (id.member & 3);
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gc[b][i]), rsX,
-                                    ob + (unsigned)(((i & 3) + 8 * (i >> 2)) * D + 32 * b) * 4u, 0, 0);
+                                    own ? OOB : ob + (unsigned)(((i & 3) + 8 * (i >> 2)) * D + 32 * b) * 4u, 0, 0);
+                            }
+                        if (kh == (id.member >> 2)) {
+                            float* const o = OWNP + (4 * h) * D + 64 * sl + l31;
+#define T2_OWN(G_)                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                   \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) o[t * D + 32 * b] = gc[b][4 * (G_) + t];
+                            switch (id.member & 3) {
+                                case 0: T2_OWN(0) break;
+                                case 1: T2_OWN(1) break;
+                                case 2: T2_OWN(2) break;
+                                default: T2_OWN(3) break;
+                            }
+#undef T2_OWN
+                        }
                     }
                 }
             }
             GE2E_PROF(7);
         }
+#ifdef GE2E_T2_GA_LATE
+        if (want_grad)
+            {   // GE's centroid fragments (k-group form): requested here, they land under GC
+                GE2E_T2_LANE();
+                {
+#pragma unroll
+                    for (int i = 0; i < NTI; ++i) {
+                        const int dt = T2_DT(i);
+                        const bool on = dt < NT;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
+                            ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
+                            ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
+                        }
+                    }
+                }
+            }
+#endif
         GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under GE and the next A1
+        GE2E_PROF(9);
         if (want_grad) {
             // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
             // The G fragments of the next row block and this block's epilogue operands are requested before the MFMAs.
@@ -808,33 +851,30 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                         h4 eh[NTI], el[NTI];
 #pragma unroll
                         for (int i = 0; i < NTI; ++i) {
-                            const int eo = r * P + min(16 * (wid + 8 * i), D - 16) + 4 * q;
+                            const int eo = r * P + min(16 * T2_DT(i), D - 16) + 4 * q;
                             eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
                             el[i] = *reinterpret_cast<const h4*>(ETl + eo);
                         }
-                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  One tile at a time: chain, settle, epilogue
+                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  
 #pragma unroll
                         for (int i = 0; i < NTI; ++i) {
                             f32x4 acc = acc_zero4();
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2)
                                 mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
-                            T2_SETTLE16_1(acc);
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                T2_KEEP(gb[rb & 1][s2][0]); T2_KEEP(gb[rb & 1][s2][1]); T2_KEEP(ga[i][s2][0]); T2_KEEP(ga[i][s2][1]);
-                            }
                             held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
                                                       fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
                                                       fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
                                                       fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
                         }
+                        if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
                         __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
                     }
                 }
 #undef T2_GE_LOAD
             }
         }
+        GE2E_PROF(10);
         // the next iteration's A rewrites the ET images and the stage inside the X block
         __syncthreads();
         GE2E_PROF(8);

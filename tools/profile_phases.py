@@ -30,7 +30,8 @@ PHASES = {
              "wait 2 (partial gradients of prev)", "P8(prev) reduce -> KJ, dE complete"],
     "team": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
               "B requests, X, partials requested + barrier", "S softmax, G images + barrier",
-              "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "GE + end barrier"],
+              "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "end barrier",
+              "next rows requested", "GE"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }

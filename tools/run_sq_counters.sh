@@ -10,7 +10,7 @@ for impl in ${IMPLS:-auto team}; do
              "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU"; do
     out=$root/gpurun_out/sq_${impl}_$i
-    rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --impl $impl > /dev/null 2> $out.log
+    rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --impl $impl > /dev/null 2> $out.log
     i=$((i+1))
   done
 done

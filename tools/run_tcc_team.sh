@@ -8,7 +8,7 @@ impl=${IMPL:-team}
 out=$root/gpurun_out
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_64B_sum TCC_READ_sum TCC_WRITE_sum" "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $set --output-format csv -d $out/tcc_${impl}_$i -- python3 $root/bench.py --impl $impl --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/tcc_${impl}_$i.log
+  rocprofv3 --pmc $set --output-format csv -d $out/tcc_${impl}_$i -- python3 $root/bench.py --impl $impl --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> $out/tcc_${impl}_$i.log
   i=$((i+1))
 done
 IMPL=$impl python3 - <<PY
