@@ -49,9 +49,6 @@ constexpr int AUX_NT = 2;
 #ifndef GE2E_T2_DE_AUX
 #define GE2E_T2_DE_AUX 2      // cache policy of the dE stores (tools/bench_variants.py sweeps it)
 #endif
-#ifndef GE2E_T2_STAGGER_MOD
-#define GE2E_T2_STAGGER_MOD 0
-#endif
 // column tile i of this wave in GE / dE.  Two tiles per wave (D > 128): ADJACENT tiles, so that after the half-row
 // exchange at the end of GE a lane pair-of-tiles covers whole 128-byte lines of dE (see T2_PAIR_LINES)
 #define T2_DT(i) (NTI == 2 ? 2 * wid + (i) : wid + 8 * (i))
@@ -167,6 +164,15 @@ __device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned targ
 // ---------------------------------------------------------------------------------------------
 static int team_cu_count() { return device_cu_count(); }
 
+// LDS bytes of one X half-block / of the G images for `rt` image rows (host layout and the compile-time-shape kernels)
+constexpr unsigned team_xb_bytes(int rt, int D) {
+    unsigned xb = (unsigned)rt * XP * 4;               // X half-blocks; the first also holds the KJ rows [8][D] of phase F
+    if (xb < 16u * D * 4) xb = 16u * D * 4;            // + the member's own slice of its partial gC [8][D]; the second stages
+    if (xb < 2u * 8 * (D + STGPAD) * 2) xb = 2u * 8 * (D + STGPAD) * 2;   // the centroid for its k-group form: [hi, lo][8][D + 32] halfs
+    return xb;
+}
+constexpr unsigned team_g_bytes(int rt) { return 2u * rt * GP * 2; }
+
 TeamKWs team_layout(int N, int M, int D) {
     TeamKWs L{};
     L.spm = (N + TEAM - 1) / TEAM;
@@ -175,10 +181,8 @@ TeamKWs team_layout(int N, int M, int D) {
     L.head_bytes = (unsigned)align_up(sizeof(TeamCtl) + 64 * sizeof(TeamKFlags), 256);
     const int P = D + 16;
     const size_t et = (size_t)2 * L.rt * P * 2;
-    size_t xb = (size_t)L.rt * XP * 4;                 // X half-blocks; the first also holds the KJ rows [8][D] of phase F,
-    if (xb < (size_t)16 * D * 4) xb = (size_t)16 * D * 4; // + the member's own slice of its partial gC [8][D]; the second stages the centroid for its k-group form:
-    if (xb < (size_t)2 * 8 * (D + STGPAD) * 2) xb = (size_t)2 * 8 * (D + STGPAD) * 2;   // [hi, lo][8 slots][D + 32] halfs
-    const size_t g = (size_t)2 * L.rt * GP * 2;        // G images
+    const size_t xb = team_xb_bytes(L.rt, D);
+    const size_t g = team_g_bytes(L.rt);
     L.xb_bytes = (unsigned)xb;
     L.g_bytes = (unsigned)g;
     L.lds_bytes = et + 2 * xb + g + (size_t)(L.rt * 8 + NC * 4 + 32 + 16) * sizeof(float);
@@ -228,10 +232,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
     _Float16* const ETl = ETh + RT * P;
     float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
-    float* const XB1 = XB0 + L.xb_bytes / 4;
-    _Float16* const Gh = reinterpret_cast<_Float16*>(XB1 + L.xb_bytes / 4);
+    // compile-time shape: every LDS offset is an immediate (fewer scalars to keep -- the kernel spills SGPRs)
+    const unsigned xb_bytes = RBT ? team_xb_bytes(16 * RBT, D) : L.xb_bytes;
+    const unsigned g_bytes = RBT ? team_g_bytes(16 * RBT) : L.g_bytes;
+    float* const XB1 = XB0 + xb_bytes / 4;
+    _Float16* const Gh = reinterpret_cast<_Float16*>(XB1 + xb_bytes / 4);
     _Float16* const Gl = Gh + RT * GP;
-    float* const RS = reinterpret_cast<float*>(reinterpret_cast<char*>(Gh) + L.g_bytes);   // [RT][8]
+    float* const RS = reinterpret_cast<float*>(reinterpret_cast<char*>(Gh) + g_bytes);   // [RT][8]
     float* const CST = RS + RT * 8;                                // [64][4]  1/|c|, kappa, |s|, |s|^2 of every slot
     float* const RED = CST + NC * 4;                               // [32]
     int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
@@ -312,15 +319,29 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const bool dact = d4 < D;                                           \
     (void)l15; (void)q; (void)d4; (void)dact
 
-#ifdef GE2E_T2_STAGGER
-    // teams start out of phase: GE2E_T2_STAGGER x 64 cycles per team index
-    for (int i = 0; i < (GE2E_T2_STAGGER_MOD ? id.team % GE2E_T2_STAGGER_MOD : id.team); ++i) __builtin_amdgcn_s_sleep(GE2E_T2_STAGGER);
-#endif
     GE2E_PROF_DECL(12)
     GE2E_T2_LOAD_ROWS(id.team);
+    const TeamId id_outer = id;
     int wslot = 0;
     bool failed = false;
+    const int wid_outer = wid, member_outer = id.member, tid_outer = tid, m_outer = M;
     for (int seq = 0;; ++seq) {
+        // wave- and member-derived scalars are re-derived in every iteration from opaque copies: as loop invariants hipcc
+        // precomputes ~130 of them in front of the loop, spills them to VGPR lanes and reads them back one v_readlane at
+        // a time (184 per iteration and wave); an s_mul / s_add where the value is needed is cheaper
+        int wid_o = wid_outer, mem_o = member_outer, tid_o = tid_outer, m_o = m_outer;
+        asm volatile("" : "+s"(wid_o), "+s"(mem_o), "+v"(tid_o), "+s"(m_o));
+        const int wid = wid_o, tid = tid_o, lane = tid & 63, M = m_o, NM = N * M;
+        TeamId id = id_outer;
+        id.member = mem_o;
+        const int j0 = id.member * spm;
+        const int my_spm = max(0, min(spm, N - j0));
+        const int R_my = my_spm * M;
+        const bool has_spk = wid < my_spm;
+        const int j = j0 + wid;
+        const int kslot = 8 * id.member + wid;
+        const int rbase = wid * M;
+        const int tX = wid & 3, khX = wid >> 2;
         const int bi = id.team + seq * id.nct;          // batch started in this iteration
         const bool have_cur = bi < p.B, have_prev = seq > 0;
         if (!have_cur && !have_prev) break;
@@ -681,38 +702,46 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ================
         // The sums are formed IN the held registers and stored from there: nothing writes those registers again before
         // the next GE.  (A store's data registers must not be reused soon after it: with the memory pipe backed up a
-        // queued store reads its data late.)  One row block per step of GC's loop -- the stores' issue slots sit under
-        // its MFMAs instead of forming a phase of their own (stamped: 2.8 k cycles for the older wave of a SIMD, 6 k
-        // for the younger); the last iteration, which has no GC, sends them in one go.
-#define T2_DE_STEP(RB_)                                                                                          \
-    do {                                                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < NTI; ++i_) {                                                     \
-            /* paired tiles hold whole lines (T2_PAIR_LINES): row 8 i + (l15 & 7), columns from the lane's half */ \
-            const int r_ = NTI == 2 ? 16 * (RB_) + 8 * i_ + (l15 & 7) : 16 * (RB_) + l15;                        \
-            const int c_ = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i_) + 4 * q;               \
-            const int loc_ = min((r_ * L.mul_m) >> 16, 7);                                                       \
-            const float4 kj_ = *reinterpret_cast<const float4*>(KJ + loc_ * D + min(c_, D - 4));                 \
-            const bool ok_ = r_ < R_my && T2_DT(i_) < NT;                                                        \
-            held[i_][RB_].x += kj_.x; held[i_][RB_].y += kj_.y; held[i_][RB_].z += kj_.z; held[i_][RB_].w += kj_.w; \
-            bstore4<GE2E_T2_DE_AUX>(rsGp, ok_ ? (unsigned)((j0 * M + r_) * D + c_) * 4u : OOB, held[i_][RB_]);   \
-        }                                                                                                        \
+        // queued store reads its data late.)  All KJ reads first, then the sums and stores: written as one loop hipcc
+        // recycles ONE temporary and serialises ten LDS round trips per wave (2.8 k cycles for the older wave of a SIMD,
+        // 6 k for the younger).  Tried and dropped: the stores under GC's MFMAs -- the wave blocks at store issue and
+        // GC went from 6 k to 10 k cycles (-7 % overall).
+#define T2_DE_STORES()                                                                                                     \
+    do {                                                                                                                   \
+            GE2E_T2_LANE();                                                                                                \
+_Pragma("unroll")                                                                                                          \
+            for (int i = 0; i < NTI; ++i) {                                                                                \
+                float4 kjv[RBC];                                                                                           \
+_Pragma("unroll")                                                                                                          \
+                for (int rb = 0; rb < RBC; ++rb)                                                                           \
+                    if (CT_DE || rb < RBr) {                                                                               \
+                                                                                                                           \
+                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
+                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
+                        kjv[rb] = *reinterpret_cast<const float4*>(KJ + min((r * L.mul_m) >> 16, 7) * D + min(c, D - 4));  \
+                    }                                                                                                      \
+_Pragma("unroll")                                                                                                          \
+                for (int rb = 0; rb < RBC; ++rb)                                                                           \
+                    if (CT_DE || rb < RBr) {                                                                               \
+                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
+                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
+                        const bool ok = r < R_my && T2_DT(i) < NT;                                                         \
+                        held[i][rb].x += kjv[rb].x; held[i][rb].y += kjv[rb].y;                                            \
+                        held[i][rb].z += kjv[rb].z; held[i][rb].w += kjv[rb].w;                                            \
+                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + c) * 4u : OOB, held[i][rb]);      \
+                    }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
     } while (0)
-#ifdef GE2E_T2_DE_IN_GC   /* tried: stores under GC's MFMAs -- 7 % slower (the wave blocks at store issue, GC 6 k -> 10 k cycles) */
-        const bool de_in_gc = want_grad && have_prev && have_cur && 64 * (wid & 3) < D;   // this wave runs GC's loop
-#else
-        constexpr bool de_in_gc = false;
-#endif
-        if (want_grad && have_prev && !de_in_gc) {
-            GE2E_T2_LANE();
-#pragma unroll
-            for (int rb = 0; rb < RBC; ++rb)
-                if (CT_DE || rb < RBr) T2_DE_STEP(rb);
-        }
+        // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
+        // stores wait to issue.  Tried and dropped: the stores under GC's MFMAs (GC 6 k -> 10 k cycles, -7 % overall);
+        // the younger wave of every SIMD running GC first and storing after it (its GC + stores take the same 11 k).
+        if (want_grad && have_prev) T2_DE_STORES();
+#undef T2_DE_STORES
         GE2E_PROF(6);
         if (!have_cur) break;
 
         if (want_grad) {
-#ifndef GE2E_T2_GA_LATE
             {   // GE's centroid fragments (k-group form): requested here, they land under GC
                 GE2E_T2_LANE();
                 {
@@ -729,7 +758,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     }
                 }
             }
-#endif
             // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
             {
                 GE2E_T2_LANE();
@@ -755,14 +783,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     for (int s = 0; s < RBC; ++s) {
                         if (CT_GC || s < RBr) {
                             if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
-                            if (de_in_gc) T2_DE_STEP(s);
 #pragma unroll
                             for (int b = 0; b < 2; ++b) mfma32x3(gc[b], gf[s & 1][0], gf[s & 1][1], ef[s & 1][b][0], ef[s & 1][b][1]);
                             __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
                         }
                     }
 #undef T2_GC_LOAD
-#undef T2_DE_STEP
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -804,25 +830,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             }
             GE2E_PROF(7);
         }
-#ifdef GE2E_T2_GA_LATE
-        if (want_grad)
-            {   // GE's centroid fragments (k-group form): requested here, they land under GC
-                GE2E_T2_LANE();
-                {
-#pragma unroll
-                    for (int i = 0; i < NTI; ++i) {
-                        const int dt = T2_DT(i);
-                        const bool on = dt < NT;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
-                            ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
-                            ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
-                        }
-                    }
-                }
-            }
-#endif
         GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under GE and the next A1
         GE2E_PROF(9);
         if (want_grad) {
