@@ -167,7 +167,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
 
     GE2E_PROF_DECL(10)
     bool have_sums = false;   // speaker sums of the current batch already sit in the workspace
+    const int wid_outer = wid, m_outer = M, n_outer = N, spt_outer = spt, ntiles_outer = ntiles, tid_outer = tid;
     for (int bi = blockIdx.x; bi < p.B; bi += gridDim.x) {
+        // wave- and shape-derived scalars are re-derived per batch from opaque copies: as loop invariants hipcc precomputes
+        // ~130 of them in front of the loop, spills them to VGPR lanes and reads them back one v_readlane at a time
+        int wid_o = wid_outer, m_o = m_outer, n_o = n_outer, spt_o = spt_outer, nt_o = ntiles_outer, tid_o = tid_outer;
+        asm volatile("" : "+s"(wid_o), "+s"(m_o), "+s"(n_o), "+s"(spt_o), "+s"(nt_o), "+v"(tid_o));
+        const int wid = wid_o, M = m_o, N = n_o, NM = N * M, spt = spt_o, ntiles = nt_o, tid = tid_o;
+        const int kh = wid >> 2, sl = wid & 3;
+        const bool slice_on = 64 * sl < D;
         const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
         const __amdgpu_buffer_rsrc_t rsE2s = rsE;
         const __amdgpu_buffer_rsrc_t rsE3 = rsE;
