@@ -23,17 +23,18 @@ unsigned long long* g_prof = nullptr;  // diagnostic build only
 
 bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 && D >= 1; }
 
-// AUTO at shapes both accept (measured at N=64, M=10, D=256, interleaved in one process, tools/compare_impls.py):
-// the eight-CU team kernel wins up to B ~ 200 (27 us vs 118 us at B = 1, 100 us vs 131 us at B = 128), the
-// one-workgroup-per-batch kernel wins in between (B = 256: 162 us vs 178 us), and from B ~ 2000 the two tie in time
-// (B = 4096: 2.39 ms both) while the team kernel moves 1.65x instead of 2.5x the algorithmic bytes: it takes those too.
-constexpr int kTeamMaxB = 192, kTeamMinLargeB = 2048;
+// AUTO at shapes both accept (measured at N=64, M=10, D=256, interleaved in one process, tools/compare_impls.py,
+// profiles/r02_team_vs_fused_split_by_B.txt): the eight-CU team kernel wins everywhere (28 us vs 117 us at B = 1,
+// 96 vs 133 us at B = 128, 245 vs 298 us at B = 384, 612 vs 619 us at B = 1024, 2.32 vs 2.40 ms at B = 4096, and it moves
+// 1.4x instead of 2.5x the algorithmic bytes) except where the one-workgroup-per-batch kernel just fills the chip
+// once: B = 256, 166 vs 173 us.
+constexpr int kSplitMinB = 208, kSplitMaxB = 256;
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
-            if ((B <= kTeamMaxB || B >= kTeamMinLargeB) && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
+            if (!(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;

@@ -15,7 +15,7 @@ impls = sys.argv[1:] or ["fused_split", "team"]
 dev = torch.device("cuda:0")
 N, M, D = 64, 10, 256
 w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
-for B in (1, 8, 32, 64, 128, 256, 1024, 4096):
+for B in (1, 8, 32, 64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096):
     E = bench.synth(B, N, M, D, 1234, dev)
     out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None, dE=torch.empty_like(E), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
     ws = {i: GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", i), dev) for i in impls}
