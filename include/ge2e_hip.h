@@ -142,6 +142,15 @@ int ge2e_normalize_unperm_bwd(const float* g, const float* e, const float* rnorm
  * denominators (s5:81,88), and the argmin over thresholds (s5:93-98) are a few dozen scalar operations on the host. */
 int ge2e_eer_counts(const float* sim, int B, int N, int M, const float* thresholds, int T, int* counts, void* stream);
 
+/* Batch sampler (s1_dataset_loader.py:65-77, EmbeddingModelTTDataset.__getitem__ for the N speakers of a batch): the
+ * per-speaker spectrogram arrays (U_j, T, F), float64 as the reference stores them on disk (sv_<speaker>.npy) or float32,
+ * stay resident in ONE device buffer `store`; spk_offsets [N] (device, int64, in ELEMENTS) locate the arrays of the batch's
+ * speakers, utter_idx [N][M] and clip_start [N] (device, int32) are the draws s1:65 and s1:71 make on the host.
+ *   out [N][M][L][F] float32 = (float) array_n[utter_idx[n][m]][clip_start[n] .. + L][:]      (s1:68, 74; the cast of s2:28)
+ * The caller guarantees 0 <= utter_idx < U_n and 0 <= clip_start <= T - L (the reference's draws do); N * M <= 65535. */
+int ge2e_sample_batch(const void* store, int store_is_f64, const long long* spk_offsets, const int* utter_idx,
+                      const int* clip_start, int N, int M, int T, int L, int F, float* out, void* stream);
+
 /* ---- diagnostics (tests only): device building blocks on caller data ------------------- */
 /* A,Bm [64][256], G [64][64] (|x| <= 1) -> X [64][64] = A.Bm^T, GE [64][256] = G.A,
  * GC [64][256] = G^T.Bm through the split-fp16 MFMA tile contractions. */

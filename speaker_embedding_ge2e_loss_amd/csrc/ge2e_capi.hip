@@ -214,6 +214,14 @@ int ge2e_eer_counts(const float* sim, int B, int N, int M, const float* threshol
     return (int)launch_eer_counts(sim, B, N, M, thresholds, T, counts, (hipStream_t)stream);
 }
 
+int ge2e_sample_batch(const void* store, int store_is_f64, const long long* spk_offsets, const int* utter_idx,
+                      const int* clip_start, int N, int M, int T, int L, int F, float* out, void* stream) {
+    if (!store || !spk_offsets || !utter_idx || !clip_start || !out) return GE2E_ERR_NULL;
+    if (N < 1 || M < 1 || T < 1 || L < 1 || L > T || F < 1 || (long long)N * M > 65535) return GE2E_ERR_SHAPE;
+    return (int)launch_sample_batch(store, store_is_f64, spk_offsets, utter_idx, clip_start, N, M, T, L, F, out,
+                                    (hipStream_t)stream);
+}
+
 // GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the gated fall-back launch does the work.
 int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, const float* w, const float* b,
                                 float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,

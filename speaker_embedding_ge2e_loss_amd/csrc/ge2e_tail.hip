@@ -98,7 +98,39 @@ __global__ __launch_bounds__(256) void eer_counts_kernel(const float* __restrict
     }
 }
 
+// ---- batch sampler (s1_dataset_loader.py:65-77) ---------------------------------------------------------------------
+// The reference keeps one (U, T, F) float64 array per speaker on disk, draws M utterance indices (with replacement) and
+// one crop start per speaker on the host, slices, stacks, and casts to float32 at the encoder's door (s2:28).  Here the
+// arrays stay resident in HBM in their on-disk type and one launch gathers + casts the (N, M, L, F) batch:
+//   out[n][m][l][f] = (float) store[spk_off[n] + (utt[n][m] * T + clip[n] + l) * F + f]
+// One thread per output element, consecutive threads along (l, f): the L * F crop of an utterance is contiguous in the
+// store, so reads and writes are both fully coalesced.  HBM-bound: 8 (or 4) bytes in, 4 out per element.
+template <typename T>
+__global__ __launch_bounds__(256) void sample_batch_kernel(const T* __restrict__ store, const long long* __restrict__ spk_off,
+                                                           const int* __restrict__ utt, const int* __restrict__ clip,
+                                                           int M, int Tfr, int L, int F, float* __restrict__ out) {
+    const int nm = blockIdx.y, n = nm / M;
+    const size_t crop = (size_t)L * F;
+    const T* src = store + spk_off[n] + ((size_t)utt[nm] * Tfr + clip[n]) * F;
+    float* dst = out + (size_t)nm * crop;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < crop; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
 }  // namespace
+
+hipError_t launch_sample_batch(const void* store, int is_f64, const long long* spk_off, const int* utt, const int* clip,
+                               int N, int M, int Tfr, int L, int F, float* out, hipStream_t stream) {
+    const size_t crop = (size_t)L * F;
+    unsigned gx = (unsigned)((crop + 255) / 256);
+    if (gx > 64) gx = 64;
+    const dim3 grid(gx, (unsigned)(N * M));
+    if (is_f64)
+        sample_batch_kernel<double><<<grid, 256, 0, stream>>>(static_cast<const double*>(store), spk_off, utt, clip, M, Tfr, L, F, out);
+    else
+        sample_batch_kernel<float><<<grid, 256, 0, stream>>>(static_cast<const float*>(store), spk_off, utt, clip, M, Tfr, L, F, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_tail_fwd(const float* y, const int* src, int rows, int D, float* e, float* rn, hipStream_t stream) {
     const int wpb = 256 / kWave;

@@ -10,4 +10,7 @@ hipError_t launch_tail_bwd(const float* g, const float* e, const float* rn, cons
 hipError_t launch_eer_counts(const float* S, int B, int N, int M, const float* thr, int T, int* counts,
                              hipStream_t stream);
 
+hipError_t launch_sample_batch(const void* store, int is_f64, const long long* spk_off, const int* utt, const int* clip,
+                               int N, int M, int Tfr, int L, int F, float* out, hipStream_t stream);
+
 }  // namespace ge2e
