@@ -49,7 +49,8 @@ extern "C" {
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
 #define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, the member's rows resident in LDS: E is
                                    read once.  Falls back to FUSED_SPLIT inside the same call (a gated second
-                                   launch) if the teams cannot form or a hand-off times out                   */
+                                   launch) if the teams cannot form or a hand-off times out.  AUTO leaves it out when
+                                   GE2E_AUTO_NO_TEAM=1 is in the environment (a process sharing the GPU)      */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */

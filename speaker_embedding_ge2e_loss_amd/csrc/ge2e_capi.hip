@@ -3,6 +3,7 @@
 #include "../../include/ge2e_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include "ge2e_common.hpp"
 #include "ge2e_generic.hpp"
@@ -30,11 +31,19 @@ bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 &&
 // once: B = 256, 166 vs 173 us.
 constexpr int kSplitMinB = 208, kSplitMaxB = 256;
 
+// The team kernel wants its workgroups co-resident.  It survives a busy device (bounded spins, then the gated fall-back
+// launch redoes the call), but a process that KNOWS it shares the GPU -- several streams or processes launching at once --
+// saves those spins by taking the team kernel out of AUTO: GE2E_AUTO_NO_TEAM=1 in the environment (read per call).
+bool auto_may_team() {
+    const char* e = getenv("GE2E_AUTO_NO_TEAM");
+    return !(e && e[0] && e[0] != '0');
+}
+
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
-            if (!(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
+            if (!(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D) && auto_may_team()) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;

@@ -75,6 +75,17 @@ def test_workspace_and_impl_queries(lib):
         assert lib.ge2e_workspace_bytes(*shape, 0, impl) == lib.ge2e_workspace_bytes(*shape, 0, 0)
 
 
+def test_auto_leaves_the_team_kernel_out_on_request(lib, monkeypatch):
+    """GE2E_AUTO_NO_TEAM=1 (a process that shares the GPU): AUTO resolves to the one-workgroup-per-batch kernel; an
+    explicit impl=team is still honoured.  Read per call, no library state."""
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["team"]
+    monkeypatch.setenv("GE2E_AUTO_NO_TEAM", "1")
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["fused_split"]
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, _lib.IMPLS["team"]) == _lib.IMPLS["team"]
+    monkeypatch.setenv("GE2E_AUTO_NO_TEAM", "0")
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["team"]
+
+
 def test_product_refuses_cpu_tensors():
     import torch
     from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
