@@ -126,6 +126,12 @@ int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const flo
 int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
                        const float* g_per, float* d_sim, void* stream);
 
+/* What `loss.backward()` (s4:200) does with the results of ge2e_loss_fwd_bwd: scale by the incoming gradient g (device;
+ * g_count = 1 for a scalar loss or B for a per-batch loss vector) in ONE launch:
+ *   gE [B][N][M][D] = g[b] dE[b]   (NULL: skip);   gw [1] = sum_b g[b] dw[b];   gb [1] = sum_b g[b] db[b]   (NULL: skip) */
+int ge2e_scale_grads(const float* dE, const float* dw, const float* db, const float* g, int g_count, int B, int N, int M,
+                     int D, float* gE, float* gw, float* gb, void* stream);
+
 /* ---- the callers either side of the loss ---------------------------------------------------------
  * Encoder tail: the L2-normalisation that ends the encoder's forward (s2_model_GE2E_loss_speach_embed.py:34), the
  * un-permute gather `embeddings[unperm]` (s4_train_embed_model.py:186) and the (N,M,D) reshape (s4:189) in one pass:

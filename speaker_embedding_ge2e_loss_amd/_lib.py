@@ -49,6 +49,7 @@ PROTOTYPES = {
     "ge2e_normalize_unperm": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ge2e_normalize_unperm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_eer_counts": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp]),
+    "ge2e_scale_grads": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ge2e_sample_batch": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_selftest_team_fallback": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
                                               C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),

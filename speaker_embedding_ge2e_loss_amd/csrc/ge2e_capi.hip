@@ -204,6 +204,13 @@ int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int var
     return (int)launch_calc_loss_bwd(sim, B, N, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
 }
 
+int ge2e_scale_grads(const float* dE, const float* dw, const float* db, const float* g, int g_count, int B, int N, int M,
+                     int D, float* gE, float* gw, float* gb, void* stream) {
+    if (!g || (gE && !dE) || (gw && !dw) || (gb && !db) || (!gE && !gw && !gb)) return GE2E_ERR_NULL;
+    if (B < 1 || N < 1 || M < 1 || D < 1 || (g_count != 1 && g_count != B)) return GE2E_ERR_SHAPE;
+    return (int)launch_scale_grads(dE, dw, db, g, g_count, B, (size_t)N * M * D, gE, gw, gb, (hipStream_t)stream);
+}
+
 int ge2e_normalize_unperm(const float* y, const int* src, int rows, int D, float* e, float* rnorm, void* stream) {
     if (!y || !e || !rnorm) return GE2E_ERR_NULL;
     if (rows < 1 || D < 1) return GE2E_ERR_SHAPE;

@@ -167,7 +167,53 @@ int grid_for(size_t items, int per_block) {
     return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
 }
 
+// autograd's side of GE2ELoss.backward: the fused launch has produced dE, dw, db per batch; the incoming gradient g
+// ([1] for a single (N,M,D) batch, [B] for a batched loss vector) scales them.  One launch instead of five torch ops:
+//   gE[b] = g[b] dE[b];  gw = sum_b g[b] dw[b];  gb = sum_b g[b] db[b]   (the sums in one wave of block 0, fixed order)
+__global__ __launch_bounds__(256) void scale_grads_kernel(const float* __restrict__ dE, const float* __restrict__ dw,
+                                                          const float* __restrict__ db, const float* __restrict__ g,
+                                                          int gB, int B, size_t per_batch, float* __restrict__ gE,
+                                                          float* __restrict__ gw, float* __restrict__ gb) {
+    if (gE) {
+        const size_t total = (size_t)B * per_batch;
+        if ((per_batch & 3) == 0) {
+            const size_t n4 = total / 4, p4 = per_batch / 4;
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+                const float s = g[gB == 1 ? 0 : i / p4];
+                const float4 v = reinterpret_cast<const float4*>(dE)[i];
+                reinterpret_cast<float4*>(gE)[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+            }
+        } else {
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+                gE[i] = dE[i] * g[gB == 1 ? 0 : i / per_batch];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kWave && (gw || gb)) {
+        float a = 0.f, c = 0.f;
+        for (int i = threadIdx.x; i < B; i += kWave) {
+            const float s = g[gB == 1 ? 0 : i];
+            if (gw) a = fmaf(dw[i], s, a);
+            if (gb) c = fmaf(db[i], s, c);
+        }
+        a = wave_sum(a);
+        c = wave_sum(c);
+        if (threadIdx.x == 0) {
+            if (gw) *gw = a;
+            if (gb) *gb = c;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_scale_grads(const float* dE, const float* dw, const float* db, const float* g, int gB, int B,
+                              size_t per_batch, float* gE, float* gw, float* gb, hipStream_t stream) {
+    size_t blocks = gE ? ((size_t)B * per_batch / 4 + 255) / 256 : 1;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_grads_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dE, dw, db, g, gB, B, per_batch, gE, gw, gb);
+    return hipGetLastError();
+}
 
 hipError_t launch_utt_centroids(const float* E, int B, int N, int M, int D, float* U, hipStream_t stream) {
     hipLaunchKernelGGL(utt_centroids_kernel, dim3(grid_for((size_t)B * N * D, 256)), dim3(256), 0, stream, E, B * N, M, D, U);

@@ -12,4 +12,7 @@ hipError_t launch_cos_bwd(const float* E, const float* C, const float* cosv, con
 hipError_t launch_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* gloss,
                                 const float* gper, float* dS, hipStream_t stream);
 
+hipError_t launch_scale_grads(const float* dE, const float* dw, const float* db, const float* g, int gB, int B,
+                              size_t per_batch, float* gE, float* gw, float* gb, hipStream_t stream);
+
 }  // namespace ge2e

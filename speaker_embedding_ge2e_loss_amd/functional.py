@@ -91,12 +91,13 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
             raise RuntimeError(f"{name} is on {t.device}, embeddings on {dev}: raw pointers cross the C ABI, all on one device")
     if out is None:
         f32 = dict(dtype=torch.float32, device=dev)
+        sc = torch.empty(3 if need_grad else 1, B, **f32)  # loss | dw | db in one allocation
         out = LossOutputs(
-            loss=torch.empty(B, **f32),
+            loss=sc[0],
             per=torch.empty(B, N, M, **f32) if need_per else None,
             dE=torch.empty(B, N, M, D, **f32) if need_grad else None,
-            dw=torch.empty(B, **f32) if need_grad else None,
-            db=torch.empty(B, **f32) if need_grad else None)
+            dw=sc[1] if need_grad else None,
+            db=sc[2] if need_grad else None)
     v, im = _lib.VARIANTS[variant], _lib.IMPLS[impl]
     need = lib.ge2e_workspace_bytes(B, N, M, D, v, im)
     if workspace is None:
@@ -387,16 +388,22 @@ class _GE2ELossFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         dE, dw, db = ctx.saved_tensors
-        g = grad_out.reshape(-1).to(torch.float32)  # (1,) or (B,)
-        gE = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gE = dE * g.view(-1, 1, 1, 1)
-            if ctx.squeeze:
-                gE = gE[0]
-        if ctx.needs_input_grad[1]:
-            gw = (dw * g).sum().reshape(ctx.w_shape)
-        if ctx.needs_input_grad[2]:
-            gb = (db * g).sum().reshape(ctx.b_shape)
+        g = grad_out.reshape(-1).to(torch.float32).contiguous()  # (1,) or (B,)
+        B, N, M, D = dE.shape
+        need_e, need_w, need_b = ctx.needs_input_grad[:3]
+        # one launch: gE = g dE, gw = sum g dw, gb = sum g db (no host sync; out of place, so a retained graph may run again)
+        gE = torch.empty_like(dE) if need_e else None
+        gwb = torch.empty(2, dtype=torch.float32, device=dE.device) if (need_w or need_b) else None
+        with torch.cuda.device(dE.device):
+            code = _lib.load().ge2e_scale_grads(
+                dE.data_ptr(), dw.data_ptr(), db.data_ptr(), g.data_ptr(), g.numel(), B, N, M, D,
+                gE.data_ptr() if need_e else None, gwb.data_ptr() if need_w else None,
+                gwb.data_ptr() + 4 if need_b else None, _stream_ptr(dE))
+        _lib.check(code, "ge2e_scale_grads")
+        if need_e and ctx.squeeze:
+            gE = gE[0]
+        gw = gwb[0].reshape(ctx.w_shape) if need_w else None
+        gb = gwb[1].reshape(ctx.b_shape) if need_b else None
         return gE, gw, gb, None, None, None, None
 
 
