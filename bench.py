@@ -311,9 +311,9 @@ def main():
         impl1 = GF.resolve_impl(1, N, M, D, variant, args.impl)
         ws1 = GF.alloc_workspace(GF.workspace_bytes(1, N, M, D, variant, impl1), dev)
         call1 = lambda: GF.loss_fwd_bwd(e1, w, b, variant=variant, impl=impl1, out=o1, workspace=ws1)  # noqa: E731
-        for _ in range(5):
+        for _ in range(10):
             call1()
-        extra["latency_b1_us"] = float(np.mean(time_launches(call1, 20))) * 1e3
+        extra["latency_b1_us"] = float(np.median(time_launches(call1, 100))) * 1e3   # median: host jitter is not the kernel
         extra["latency_b1_impl"] = impl1
 
         # what a user of the reference's class pays per training step at B=1: GE2ELoss.forward + loss.backward()
@@ -327,9 +327,9 @@ def main():
             mod.zero_grad(set_to_none=True)
             mod(em).backward()
 
-        for _ in range(5):
+        for _ in range(10):
             module_step()
-        extra["latency_module_b1_us"] = float(np.mean(time_launches(module_step, 20))) * 1e3
+        extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
 
         # the exact-fp32 kernel beside the split-fp16 one (same workload; fewer steps)
         if impl in SPLIT_IMPLS and world == 1:
