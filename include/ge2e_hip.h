@@ -52,6 +52,10 @@ extern "C" {
                                    launch) if the teams cannot form or a hand-off times out.  AUTO leaves it out when
                                    GE2E_AUTO_NO_TEAM=1 is in the environment (a process sharing the GPU)      */
 
+#define GE2E_IMPL_WAVE 6        /* one WAVE per batch, the batch in registers, exact fp32, no workspace: the reference's
+                                   own shapes (a few dozen rows: N <= 2..6 depending on M in {2,3,4,5,6,8,10,16},
+                                   D <= 256, D % 4 == 0)                                                        */
+
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */
 #define GE2E_ERR_SHAPE (-2)     /* B,N,D < 1 or M < 2 (M = 1 divides by zero in

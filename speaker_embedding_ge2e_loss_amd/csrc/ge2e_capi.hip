@@ -13,6 +13,7 @@
 #include "ge2e_tiled.hpp"
 #include "ge2e_team_kernel.hpp"
 #include "ge2e_tail.hpp"
+#include "ge2e_wave.hpp"
 
 using namespace ge2e;
 
@@ -43,6 +44,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
+            if (wave_supports(N, M, D)) return GE2E_IMPL_WAVE;   // a few dozen rows: one wave per batch, exact fp32
             if (!(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D) && auto_may_team()) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
@@ -51,6 +53,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_supports(N, M, D) ? GE2E_IMPL_FUSED_SPLIT : GE2E_ERR_IMPL;
         case GE2E_IMPL_TILED: return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_ERR_IMPL;
         case GE2E_IMPL_TEAM: return team_supports(N, M, D) ? GE2E_IMPL_TEAM : GE2E_ERR_IMPL;
+        case GE2E_IMPL_WAVE: return wave_supports(N, M, D) ? GE2E_IMPL_WAVE : GE2E_ERR_IMPL;
         default: return GE2E_ERR_IMPL;
     }
 }
@@ -62,6 +65,7 @@ size_t ws_bytes(int B, int N, int M, int D, int impl) {
         case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TILED: return tiled_workspace_bytes(B, N, M, D);
         case GE2E_IMPL_TEAM: return team_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_WAVE: return 0;
         default: return 0;
     }
 }
@@ -86,6 +90,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
         case GE2E_IMPL_FUSED_SPLIT: err = launch_fused_split(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TILED: err = launch_tiled(p, (hipStream_t)stream); break;
         case GE2E_IMPL_TEAM: err = launch_team(p, (hipStream_t)stream); break;
+        case GE2E_IMPL_WAVE: err = launch_wave(p, (hipStream_t)stream); break;
         default: return GE2E_ERR_IMPL;
     }
     return (int)err;

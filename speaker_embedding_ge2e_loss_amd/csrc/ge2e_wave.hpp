@@ -1,0 +1,10 @@
+// Launcher of GE2E_IMPL_WAVE (ge2e_wave.hip): one wave per batch, registers only, no workspace.
+#pragma once
+#include "ge2e_common.hpp"
+
+namespace ge2e {
+
+bool wave_supports(int N, int M, int D);
+hipError_t launch_wave(const Problem& p, hipStream_t stream);
+
+}  // namespace ge2e

@@ -20,6 +20,7 @@ TOL = {  # impl -> (loss rtol, dE rel-fro / relative max-abs, dw rtol, cos atol)
     "fused_split": (2e-5, 2e-5, 5e-5, 5e-6),
     "tiled": (2e-5, 2e-5, 5e-5, 5e-6),
     "team": (2e-5, 2e-5, 5e-5, 5e-6),
+    "wave": (5e-6, 1e-5, 2e-5, 2e-6),
     "auto": (1e-4, 1e-4, 1e-4, 1e-5),
 }
 
@@ -34,7 +35,7 @@ def GF():
 
 def impls_for(GF, B, N, M, D, variant="softmax"):
     out = []
-    for name in ("generic", "fused_f32", "fused_split", "tiled", "team"):
+    for name in ("generic", "fused_f32", "fused_split", "tiled", "team", "wave"):
         try:
             GF.resolve_impl(B, N, M, D, variant, name)
             out.append(name)
@@ -122,7 +123,10 @@ def test_config5_large(GF):
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 2, 1), (1, 2, 2, 3), (3, 5, 3, 7), (2, 7, 4, 65), (1, 65, 2, 33),
-                                   (2, 33, 9, 130), (1, 130, 3, 20), (4, 16, 16, 128), (1, 8, 40, 256)])
+                                   (2, 33, 9, 130), (1, 130, 3, 20), (4, 16, 16, 128), (1, 8, 40, 256),
+                                   # one wave per batch: every instantiated M at its largest N, small and odd D, B > grid
+                                   (5, 6, 2, 256), (3, 5, 3, 36), (9, 4, 4, 128), (2100, 4, 5, 256), (7, 3, 6, 64),
+                                   (3, 3, 8, 252), (4, 2, 10, 4), (6, 2, 16, 256), (2, 1, 16, 8)])
 @pytest.mark.parametrize("variant", ["softmax", "contrast"])
 def test_ragged_shapes(GF, shape, variant):
     """Odd sizes: N not a multiple of the wave, D not a multiple of 4, M = 2, N = 1."""
