@@ -31,6 +31,43 @@ __device__ __forceinline__ void fma4(float4& acc, const float4& a, float s) {
     acc.x = fmaf(a.x, s, acc.x); acc.y = fmaf(a.y, s, acc.y); acc.z = fmaf(a.z, s, acc.z); acc.w = fmaf(a.w, s, acc.w);
 }
 
+// K wave sums at once, stage by stage: a single DPP reduction is a chain of dependent VALU -> DPP steps with two wait
+// states each (hipcc fills them with s_nop: 9 per sum); K independent chains fill each other's slots.
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR2>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_HALF_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        auto a = GE2E_SWAP16(__float_as_uint(v[k]));
+        v[k] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        auto b = GE2E_SWAP32(__float_as_uint(v[k]));
+        v[k] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+}
+// x / max(|x|, eps) bookkeeping (ge2e_common.hpp: unit_stats) on v_rsq_f32 + one Newton step instead of a square root
+// and two IEEE divisions: rn = 1 / max(|x|, eps), kappa = clamped / true norm (0 for a zero vector)
+__device__ __forceinline__ void unit_stats_q(float sq, float eps_cos, float eps_cos2, float& rn, float& kappa) {
+    const float sqc = fmaxf(sq, eps_cos2);
+    float r = __builtin_amdgcn_rsqf(sqc);
+    r = r * (1.5f - 0.5f * sqc * r * r);
+    rn = r;
+    kappa = sq >= eps_cos2 ? 1.0f : (sq > 1e-36f ? eps_cos * __builtin_amdgcn_rsqf(sq) : 0.0f);
+}
+__device__ __forceinline__ float rcp_q(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
+
 template <int M, int NX>
 __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
     const int N = p.N, D = p.D, NM = N * M;
@@ -40,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
     const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
     const bool contrast = p.variant == 1, want_grad = p.dE != nullptr;
     const float inv_m = 1.0f / (float)M, inv_m1 = 1.0f / (float)(M - 1);
+    const float eps_cos2 = eps_cos * eps_cos;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int bi = blockIdx.x * 4 + wid; bi < p.B; bi += gridDim.x * 4) {
@@ -54,15 +92,23 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
         // speaker sums, unit centroids (s3:34-38 + the cosine's normalisation)
         float4 s[NX], ch[NX];
         float rnc[NX], kc[NX];
+        {
+            float cc[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            float4 a = e[j * M];
+            for (int j = 0; j < NX; ++j) {
+                float4 a = e[j * M];
 #pragma unroll
-            for (int i = 1; i < M; ++i) { a.x += e[j * M + i].x; a.y += e[j * M + i].y; a.z += e[j * M + i].z; a.w += e[j * M + i].w; }
-            s[j] = a;
-            const float4 c = mul4(a, inv_m);
-            unit_stats(wave_sum(dot4w(c, c)), eps_cos, rnc[j], kc[j]);
-            ch[j] = mul4(c, rnc[j]);
+                for (int i = 1; i < M; ++i) { a.x += e[j * M + i].x; a.y += e[j * M + i].y; a.z += e[j * M + i].z; a.w += e[j * M + i].w; }
+                s[j] = a;
+                ch[j] = mul4(a, inv_m);
+                cc[j] = dot4w(ch[j], ch[j]);
+            }
+            wave_sum_n<NX>(cc);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                unit_stats_q(cc[j], eps_cos, eps_cos2, rnc[j], kc[j]);
+                ch[j] = mul4(ch[j], rnc[j]);
+            }
         }
 
         float4 gC[NX], DU[NX];
@@ -77,19 +123,25 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
                 for (int i = 0; i < M; ++i) {
                     const int r = j * M + i;
                     const float4 x = e[r];
-                    float rne, ke, rnu, ku;
-                    unit_stats(wave_sum(dot4w(x, x)), eps_cos, rne, ke);
-                    const float4 eh = mul4(x, rne);
                     // leave-one-out centroid of the own speaker (s3:96-112)
                     const float4 u = make_float4((s[j].x - x.x) * inv_m1, (s[j].y - x.y) * inv_m1, (s[j].z - x.z) * inv_m1,
                                                  (s[j].w - x.w) * inv_m1);
-                    unit_stats(wave_sum(dot4w(u, u)), eps_cos, rnu, ku);
+                    // every dot product of the row on the RAW vectors, reduced together; the norms scale them afterwards
+                    float dt[NX + 2];   // x . c-hat_k (k != j; slot j: x . u), x . x, u . u
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) dt[k] = k == j ? dot4w(x, u) : dot4w(x, ch[k]);
+                    dt[NX] = dot4w(x, x);
+                    dt[NX + 1] = dot4w(u, u);
+                    wave_sum_n<NX + 2>(dt);
+                    float rne, ke, rnu, ku;
+                    unit_stats_q(dt[NX], eps_cos, eps_cos2, rne, ke);
+                    unit_stats_q(dt[NX + 1], eps_cos, eps_cos2, rnu, ku);
+                    const float4 eh = mul4(x, rne);
                     const float4 uh = mul4(u, rnu);
-                    const float cosd = wave_sum(dot4w(eh, uh));
+                    const float cosd = dt[j] * rne * rnu;
                     float c0[NX];
 #pragma unroll
-                    for (int k = 0; k < NX; ++k)
-                        c0[k] = k == j ? cosd : (k < N ? wave_sum(dot4w(eh, ch[k])) : 0.f);
+                    for (int k = 0; k < NX; ++k) c0[k] = k == j ? cosd : (k < N ? dt[k] * rne : 0.f);
 
                     // eq. (6) / eq. (7) on the row's N similarities (wave-uniform scalars)
                     const float sjj = fmaf(w, cosd + eps, bias);
@@ -101,15 +153,15 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
                             sv[k] = k < N ? fmaf(w, c0[k] + eps, bias) : -INFINITY;
                             mx = fmaxf(mx, sv[k]);
                         }
-                        float zoff = expf(log_eps - mx);   // the "+ small_err" inside the log (s3:120)
+                        float zoff = __expf(log_eps - mx);   // the "+ small_err" inside the log (s3:120)
 #pragma unroll
                         for (int k = 0; k < NX; ++k) {
-                            g[k] = expf(sv[k] - mx);          // exp(-inf) = 0 for k >= N
+                            g[k] = __expf(sv[k] - mx);        // exp(-inf) = 0 for k >= N
                             if (k != j) zoff += g[k];
                         }
-                        const float z = zoff + expf(sjj - mx);
-                        per = (mx - sjj) + logf(z);
-                        const float rz = 1.0f / z;
+                        const float z = zoff + __expf(sjj - mx);
+                        per = (mx - sjj) + __logf(z);
+                        const float rz = rcp_q(z);
 #pragma unroll
                         for (int k = 0; k < NX; ++k) g[k] = k == j ? -zoff * rz : g[k] * rz;
                     } else {
@@ -120,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
                             const float sk = fmaf(w, c0[k] + eps, bias);
                             if (k != j && k < N && sk > best) { best = sk; besti = k; }
                         }
-                        const float pos = 1.0f / (1.0f + expf(-sjj));
-                        const float neg = (N > 1) ? 1.0f / (1.0f + expf(-best)) : 0.0f;
+                        const float pos = rcp_q(1.0f + __expf(-sjj));
+                        const float neg = (N > 1) ? rcp_q(1.0f + __expf(-best)) : 0.0f;
                         per = 1.0f - pos + neg;
 #pragma unroll
                         for (int k = 0; k < NX; ++k) g[k] = k == j ? -pos * (1.0f - pos) : (k == besti ? neg * (1.0f - neg) : 0.f);
@@ -164,11 +216,15 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
 
         if (want_grad) {
             float* Gb = p.dE + (size_t)bi * NM * D + 4 * lane;
+            float gd[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) gd[j] = dot4w(gC[j], ch[j]);
+            wave_sum_n<NX>(gd);
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 if (j < N) {
                     // centroid gradient through its normalisation, + the leave-one-out sums: one row per speaker
-                    const float t = kc[j] * wave_sum(dot4w(gC[j], ch[j]));
+                    const float t = kc[j] * gd[j];
                     const float a = rnc[j] * inv_m;
                     const float4 kj = make_float4(fmaf(gC[j].x - t * ch[j].x, a, DU[j].x * inv_m1), fmaf(gC[j].y - t * ch[j].y, a, DU[j].y * inv_m1),
                                                   fmaf(gC[j].z - t * ch[j].z, a, DU[j].z * inv_m1), fmaf(gC[j].w - t * ch[j].w, a, DU[j].w * inv_m1));
