@@ -20,7 +20,8 @@ def GF():
     return functional
 
 
-@pytest.mark.parametrize("shape", [(1, 6, 10, 256), (3, 64, 10, 256), (2, 16, 8, 128), (1, 4, 16, 64)])
+@pytest.mark.parametrize("shape", [(1, 6, 10, 256), (3, 64, 10, 256), (2, 16, 8, 128), (1, 4, 16, 64),
+                                   (2100, 4, 5, 256), (37, 2, 16, 256)])   # the last two: one wave per batch
 def test_repeated_launches_are_bitwise_identical(GF, shape):
     E = orc.synth_embeddings(shape, "unit", seed=5)
     ref = orc.closed_form(E, 10.0, -5.0)
