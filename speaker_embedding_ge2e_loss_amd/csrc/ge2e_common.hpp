@@ -119,6 +119,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     auto b = GE2E_SWAP32(__float_as_uint(v));
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// K wave sums at once, stage by stage: a single DPP reduction is a chain of dependent VALU -> DPP steps with two wait
+// states each (hipcc fills them with s_nop: 9 per sum); K independent chains fill each other's slots.
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR2>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_HALF_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        auto a = GE2E_SWAP16(__float_as_uint(v[k]));
+        v[k] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        auto b = GE2E_SWAP32(__float_as_uint(v[k]));
+        v[k] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = row16_max(v);
     auto a = GE2E_SWAP16(__float_as_uint(v));

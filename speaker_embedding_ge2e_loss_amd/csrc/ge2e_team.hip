@@ -367,8 +367,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             for (int i = 0; i < MR; ++i)
                 if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
             const float4 c = scale4(s, inv_m);
-            const float sq = wave_sum(dot4(c, c));
-            const float ss = wave_sum(dot4(s, s));
+            float sqs[2] = {dot4(c, c), dot4(s, s)};
+            wave_sum_n<2>(sqs);
+            const float sq = sqs[0], ss = sqs[1];
             float rn, kap, nc;
             unit_stats_bf(sq, eps_cos, eps_cos2, rn, kap, nc);
             if (!has_spk) { rn = 0.f; kap = 0.f; nc = 0.f; }     // slots without a speaker publish zero rows
@@ -412,11 +413,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
         if (have_cur && has_spk) {
             GE2E_T2_LANE();
+            float eev[MR];      // the rows' squared norms, reduced together (independent DPP chains fill each other's wait states)
+#pragma unroll
+            for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(rowv[i], rowv[i]) : 0.f;
+            wave_sum_n<MR>(eev);
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float4 e = rowv[i];
-                    const float ee = wave_sum(dot4(e, e));
+                    const float ee = eev[i];
                     float rne, ke, ne;
                     unit_stats_bf(ee, eps_cos, eps_cos2, rne, ke, ne);
                     if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));

@@ -31,29 +31,6 @@ __device__ __forceinline__ void fma4(float4& acc, const float4& a, float s) {
     acc.x = fmaf(a.x, s, acc.x); acc.y = fmaf(a.y, s, acc.y); acc.z = fmaf(a.z, s, acc.z); acc.w = fmaf(a.w, s, acc.w);
 }
 
-// K wave sums at once, stage by stage: a single DPP reduction is a chain of dependent VALU -> DPP steps with two wait
-// states each (hipcc fills them with s_nop: 9 per sum); K independent chains fill each other's slots.
-template <int K>
-__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR1>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR2>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_HALF_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        auto a = GE2E_SWAP16(__float_as_uint(v[k]));
-        v[k] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        auto b = GE2E_SWAP32(__float_as_uint(v[k]));
-        v[k] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-    }
-}
 // x / max(|x|, eps) bookkeeping (ge2e_common.hpp: unit_stats) on v_rsq_f32 + one Newton step instead of a square root
 // and two IEEE divisions: rn = 1 / max(|x|, eps), kappa = clamped / true norm (0 for a zero vector)
 __device__ __forceinline__ void unit_stats_q(float sq, float eps_cos, float eps_cos2, float& rn, float& kappa) {
