@@ -19,6 +19,8 @@
 #include "ge2e_common.hpp"
 #include "ge2e_wave.hpp"
 
+#include <type_traits>
+
 namespace ge2e {
 
 namespace {
@@ -45,11 +47,54 @@ __device__ __forceinline__ float rcp_q(float x) {
     return r * (2.0f - x * r);
 }
 
+// Sum over the wave into an SGPR: four DPP steps inside each row of 16 lanes, two row broadcasts (lane 15 of a row into
+// the next row, lane 31 into rows 2 and 3) and one v_readlane of lane 63 -- 7 instructions a value against 12 for the
+// all-lanes form, and the result is a scalar operand.  K values stage by stage (see wave_sum_n).
+template <int K>
+__device__ __forceinline__ void wave_sum_to_sgpr(float (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR2>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_HALF_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k)   // row_bcast:15, rows 1 and 3
+        v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x142, 0xA, 0xF, false));
+#pragma unroll
+    for (int k = 0; k < K; ++k)   // row_bcast:31, rows 2 and 3
+        v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x143, 0xC, 0xF, false));
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
+}
+template <int R, int RMAX, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (R < RMAX) {
+        f(std::integral_constant<int, R>{});
+        static_for<R + 1, RMAX>(f);
+    }
+}
+template <int LANE>
+__device__ __forceinline__ float lane_put(float vec, float uniform) {   // vec[LANE] = uniform (a wave-uniform value)
+    const int u = __builtin_amdgcn_readfirstlane(__float_as_int(uniform));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(u), "n"(LANE));
+    return vec;
+}
+__device__ __forceinline__ float lane_get(float vec, int lane_id) {                  // uniform = vec[lane_id]
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vec), lane_id));
+}
+
+// Three passes per batch.  (1) per row: its N + 2 dot products on the raw vectors, reduced to scalars and dropped into
+// LANE r of N + 2 registers.  (2) ONCE for all rows, lane r = row r: norms, cosines, softmax / contrast, dL/dS, the
+// coefficients of the row's gradient (the part that every lane used to compute redundantly per row: ~60 of a row's
+// ~350 instructions).  (3) per row: its coefficients read back as scalars (v_readlane), the vector part of the gradient.
 template <int M, int NX>
-__global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
-    const int N = p.N, D = p.D, NM = N * M;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const bool act = 4 * lane < D;
+__global__ __launch_bounds__(256, (NX * M > 30 ? 1 : 2)) void ge2e_wave_kernel(Problem p) {   // 32 rows: one workgroup per
+    static_assert(NX * M <= 64, "a row per lane in pass 2");                                     // CU, AGPRs instead of scratch
+    const int N_outer = p.N, D_outer = p.D;
+    const int lane_outer = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
     const float eps = p.eps, eps_cos = p.eps_cos, log_eps = p.log_eps;
     const bool contrast = p.variant == 1, want_grad = p.dE != nullptr;
@@ -58,6 +103,14 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int bi = blockIdx.x * 4 + wid; bi < p.B; bi += gridDim.x * 4) {
+        // shape- and lane-derived values re-derived per batch from opaque copies: as loop invariants hipcc keeps every
+        // row offset and predicate mask in SGPRs, runs out, and parks them in VGPR lanes (ge2e_team.hip, hazard 8)
+        int N = N_outer, D = D_outer, lane = lane_outer;
+        asm volatile("" : "+s"(N), "+s"(D), "+v"(lane));
+        const int NM = N * M;
+        const bool act = 4 * lane < D;
+        const int jl = lane / M;                 // the speaker of "my" row in pass 2
+        const bool rowv = lane < NM;
         const float* Eb = p.E + (size_t)bi * NM * D + 4 * lane;
         float4 e[NX * M];
 #pragma unroll
@@ -80,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
                 ch[j] = mul4(a, inv_m);
                 cc[j] = dot4w(ch[j], ch[j]);
             }
-            wave_sum_n<NX>(cc);
+            wave_sum_to_sgpr<NX>(cc);
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 unit_stats_q(cc[j], eps_cos, eps_cos2, rnc[j], kc[j]);
@@ -88,115 +141,138 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
             }
         }
 
+        // ---- pass 1: T[k] lane r = x_r . c-hat_k (k != j_r) | x_r . u_r (k = j_r);  T[NX] = |x_r|^2;  T[NX + 1] = |u_r|^2
+        float T[NX + 2];
+#pragma unroll
+        for (int k = 0; k < NX + 2; ++k) T[k] = 0.f;
+        static_for<0, NX * M>([&](auto rc) {
+            constexpr int r = decltype(rc)::value, j = r / M;
+            if (j < N) {
+                const float4 x = e[r];
+                // leave-one-out centroid of the own speaker (s3:96-112)
+                const float4 u = make_float4((s[j].x - x.x) * inv_m1, (s[j].y - x.y) * inv_m1, (s[j].z - x.z) * inv_m1,
+                                             (s[j].w - x.w) * inv_m1);
+                float dt[NX + 2];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) dt[k] = k == j ? dot4w(x, u) : dot4w(x, ch[k]);
+                dt[NX] = dot4w(x, x);
+                dt[NX + 1] = dot4w(u, u);
+                wave_sum_to_sgpr<NX + 2>(dt);
+#pragma unroll
+                for (int k = 0; k < NX + 2; ++k) T[k] = lane_put<r>(T[k], dt[k]);
+            }
+            if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time: more in flight costs registers
+        });
+
+        // ---- pass 2: lane r = row r
+        float rne, ke, rnu, ku;
+        unit_stats_q(T[NX], eps_cos, eps_cos2, rne, ke);
+        unit_stats_q(T[NX + 1], eps_cos, eps_cos2, rnu, ku);
+        float c0[NX], g[NX];
+        float cosd = 0.f;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const bool own = k == jl;
+            c0[k] = k < N ? T[k] * rne * (own ? rnu : 1.0f) : 0.f;
+            cosd = own ? c0[k] : cosd;
+        }
+        const float sjj = fmaf(w, cosd + eps, bias);
+        float per;
+        if (!contrast) {
+            float sv[NX], mx = log_eps;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                sv[k] = k < N ? fmaf(w, c0[k] + eps, bias) : -INFINITY;
+                mx = fmaxf(mx, sv[k]);
+            }
+            float zoff = __expf(log_eps - mx);   // the "+ small_err" inside the log (s3:120)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                g[k] = __expf(sv[k] - mx);        // exp(-inf) = 0 for k >= N
+                zoff += k == jl ? 0.f : g[k];
+            }
+            const float z = zoff + __expf(sjj - mx);
+            per = (mx - sjj) + __logf(z);
+            const float rz = rcp_q(z);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) g[k] = k == jl ? -zoff * rz : g[k] * rz;
+        } else {
+            float best = -INFINITY;
+            int besti = -1;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const float sk = fmaf(w, c0[k] + eps, bias);
+                if (k != jl && k < N && sk > best) { best = sk; besti = k; }
+            }
+            const float pos = rcp_q(1.0f + __expf(-sjj));
+            const float neg = (N > 1) ? rcp_q(1.0f + __expf(-best)) : 0.0f;
+            per = 1.0f - pos + neg;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) g[k] = k == jl ? -pos * (1.0f - pos) : (k == besti ? neg * (1.0f - neg) : 0.f);
+        }
+        float red[3] = {0.f, 0.f, 0.f};   // loss, dw, db of my row
+        float coef = 0.f;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            if (k < N) {
+                red[1] = fmaf(g[k], c0[k] + eps, red[1]);
+                red[2] += g[k];
+                coef = fmaf(w * g[k], c0[k], coef);   // g_e . e-hat_r: every dot product is a cosine we have
+            }
+            g[k] *= w;                                // A = w dL/dS
+        }
+        red[0] = per;
+        if (!rowv) { red[0] = 0.f; red[1] = 0.f; red[2] = 0.f; }
+        if (p.per && rowv) p.per[(size_t)bi * NM + lane] = per;
+        float adl = 0.f;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) adl = k == jl ? g[k] : adl;
+        const float tl = ke * coef;                   // kap_e (g_e . e-hat)
+        const float tul = ku * cosd;                  // kap_u cos_rj: (g_u . u-hat) / A_rj
+        const float scl = adl * rnu;
+        wave_sum_to_sgpr<3>(red);
+
+        // ---- pass 3: the vector part of every row's gradient
         float4 gC[NX], DU[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) { gC[j] = z4; DU[j] = z4; }
-        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-
+        if (want_grad) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            if (j < N) {
+            for (int j = 0; j < NX; ++j) {
+                if (j < N) {
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    const int r = j * M + i;
-                    const float4 x = e[r];
-                    // leave-one-out centroid of the own speaker (s3:96-112)
-                    const float4 u = make_float4((s[j].x - x.x) * inv_m1, (s[j].y - x.y) * inv_m1, (s[j].z - x.z) * inv_m1,
-                                                 (s[j].w - x.w) * inv_m1);
-                    // every dot product of the row on the RAW vectors, reduced together; the norms scale them afterwards
-                    float dt[NX + 2];   // x . c-hat_k (k != j; slot j: x . u), x . x, u . u
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) dt[k] = k == j ? dot4w(x, u) : dot4w(x, ch[k]);
-                    dt[NX] = dot4w(x, x);
-                    dt[NX + 1] = dot4w(u, u);
-                    wave_sum_n<NX + 2>(dt);
-                    float rne, ke, rnu, ku;
-                    unit_stats_q(dt[NX], eps_cos, eps_cos2, rne, ke);
-                    unit_stats_q(dt[NX + 1], eps_cos, eps_cos2, rnu, ku);
-                    const float4 eh = mul4(x, rne);
-                    const float4 uh = mul4(u, rnu);
-                    const float cosd = dt[j] * rne * rnu;
-                    float c0[NX];
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) c0[k] = k == j ? cosd : (k < N ? dt[k] * rne : 0.f);
-
-                    // eq. (6) / eq. (7) on the row's N similarities (wave-uniform scalars)
-                    const float sjj = fmaf(w, cosd + eps, bias);
-                    float g[NX], per;
-                    if (!contrast) {
-                        float sv[NX], mx = log_eps;
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) {
-                            sv[k] = k < N ? fmaf(w, c0[k] + eps, bias) : -INFINITY;
-                            mx = fmaxf(mx, sv[k]);
-                        }
-                        float zoff = __expf(log_eps - mx);   // the "+ small_err" inside the log (s3:120)
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) {
-                            g[k] = __expf(sv[k] - mx);        // exp(-inf) = 0 for k >= N
-                            if (k != j) zoff += g[k];
-                        }
-                        const float z = zoff + __expf(sjj - mx);
-                        per = (mx - sjj) + __logf(z);
-                        const float rz = rcp_q(z);
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) g[k] = k == j ? -zoff * rz : g[k] * rz;
-                    } else {
-                        float best = -INFINITY;
-                        int besti = -1;
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) {
-                            const float sk = fmaf(w, c0[k] + eps, bias);
-                            if (k != j && k < N && sk > best) { best = sk; besti = k; }
-                        }
-                        const float pos = rcp_q(1.0f + __expf(-sjj));
-                        const float neg = (N > 1) ? rcp_q(1.0f + __expf(-best)) : 0.0f;
-                        per = 1.0f - pos + neg;
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) g[k] = k == j ? -pos * (1.0f - pos) : (k == besti ? neg * (1.0f - neg) : 0.f);
-                    }
-                    loss_acc += per;
-                    if (p.per && lane == 0) p.per[(size_t)bi * NM + r] = per;
-                    float coef = 0.f;
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) {
-                        if (k < N) {
-                            dw_acc = fmaf(g[k], c0[k] + eps, dw_acc);
-                            db_acc += g[k];
-                            coef = fmaf(w * g[k], c0[k], coef);   // g_e . e-hat_r: every dot product is a cosine we have
-                        }
-                    }
-                    if (want_grad) {
-                        const float ad = w * g[j];
-                        float4 ge = mul4(uh, ad);
+                    for (int i = 0; i < M; ++i) {
+                        const int r = j * M + i;
+                        const float4 x = e[r];
+                        const float rne_r = lane_get(rne, r), rnu_r = lane_get(rnu, r);
+                        const float4 eh = mul4(x, rne_r);
+                        const float4 uh = make_float4((s[j].x - x.x) * (inv_m1 * rnu_r), (s[j].y - x.y) * (inv_m1 * rnu_r),
+                                                      (s[j].z - x.z) * (inv_m1 * rnu_r), (s[j].w - x.w) * (inv_m1 * rnu_r));
+                        float4 ge = mul4(uh, lane_get(adl, r));
 #pragma unroll
                         for (int k = 0; k < NX; ++k) {
                             if (k != j && k < N) {
-                                const float a = w * g[k];
+                                const float a = lane_get(g[k], r);
                                 fma4(ge, ch[k], a);
                                 fma4(gC[k], eh, a);
                             }
                         }
-                        const float t = ke * coef;
-                        const float4 de = make_float4((ge.x - t * eh.x) * rne, (ge.y - t * eh.y) * rne, (ge.z - t * eh.z) * rne,
-                                                      (ge.w - t * eh.w) * rne);
-                        const float tu = ku * cosd;          // (g_u . u-hat) = A_rj cos_rj
-                        const float sc = ad * rnu;
+                        const float t = lane_get(tl, r), tu = lane_get(tul, r), sc = lane_get(scl, r);
+                        const float4 de = make_float4((ge.x - t * eh.x) * rne_r, (ge.y - t * eh.y) * rne_r, (ge.z - t * eh.z) * rne_r,
+                                                      (ge.w - t * eh.w) * rne_r);
                         const float4 du = make_float4((eh.x - tu * uh.x) * sc, (eh.y - tu * uh.y) * sc, (eh.z - tu * uh.z) * sc,
                                                       (eh.w - tu * uh.w) * sc);
                         DU[j].x += du.x; DU[j].y += du.y; DU[j].z += du.z; DU[j].w += du.w;
                         e[r] = make_float4(de.x - du.x * inv_m1, de.y - du.y * inv_m1, de.z - du.z * inv_m1, de.w - du.w * inv_m1);
+                        if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-        }
-
-        if (want_grad) {
             float* Gb = p.dE + (size_t)bi * NM * D + 4 * lane;
             float gd[NX];
 #pragma unroll
             for (int j = 0; j < NX; ++j) gd[j] = dot4w(gC[j], ch[j]);
-            wave_sum_n<NX>(gd);
+            wave_sum_to_sgpr<NX>(gd);
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 if (j < N) {
@@ -216,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void ge2e_wave_kernel(Problem p) {
             }
         }
         if (lane == 0) {
-            p.loss[bi] = loss_acc;
-            if (p.dw) p.dw[bi] = dw_acc;
-            if (p.db) p.db[bi] = db_acc;
+            p.loss[bi] = red[0];
+            if (p.dw) p.dw[bi] = red[1];
+            if (p.db) p.db[bi] = red[2];
         }
     }
 }

@@ -1,0 +1,19 @@
+import torch, sys
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from speaker_embedding_ge2e_loss_amd import functional as GF
+import bench
+dev = torch.device("cuda:0")
+for (N, M, D) in ((4, 5, 256), (2, 16, 256), (3, 8, 256), (2, 10, 256), (4, 4, 64), (6, 2, 128)):
+    for B in (1, 4096):
+        E = bench.synth(B, N, M, D, 1, dev)
+        w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+        res = {}
+        for impl in ("wave", "fused_split"):
+            out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None, dE=torch.empty_like(E), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
+            ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", impl), dev)
+            f = lambda: GF.loss_fwd_bwd(E, w, b, impl=impl, out=out, workspace=ws)
+            for _ in range(5): f()
+            torch.cuda.synchronize()
+            res[impl] = float(np.median(bench.time_launches(f, 50))) * 1e3
+        print((N, M, D), B, {k: round(v, 1) for k, v in res.items()}, flush=True)
