@@ -639,6 +639,22 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
             *reinterpret_cast<float4*>(KJ + d) = acc;
         }
     }
+    // the batch's loss / dw / db: fixed-order sums of the per-row values (k_rows wrote them two launches ago), taken by
+    // the wave of speaker 0 -- one launch fewer than a reduction kernel of its own (forward-only calls keep k_reduce)
+    if (j == 0) {
+        const float* RSb = p.ws + L.rs + (size_t)bi * NM * 8;
+        float red[3] = {0.f, 0.f, 0.f};
+        for (int r = lane; r < NM; r += kWave) {
+            const float4 v = *reinterpret_cast<const float4*>(RSb + (size_t)r * 8 + 4);   // . loss dw db
+            red[0] += v.y; red[1] += v.z; red[2] += v.w;
+        }
+        wave_sum_n<3>(red);
+        if (lane == 0) {
+            if (p.loss) p.loss[bi] = red[0];
+            if (p.dw) p.dw[bi] = red[1];
+            if (p.db) p.db[bi] = red[2];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -796,7 +812,8 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
         else
             hipLaunchKernelGGL(ge2e_tiled_ge<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
     }
-    hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
+    else   // forward only: nothing ran after k_rows that could carry the sums
+        hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
     return hipGetLastError();
 }
 
