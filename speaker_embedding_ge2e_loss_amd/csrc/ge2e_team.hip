@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
             const float4 c = scale4(s, inv_m);
             float sqs[2] = {dot4(c, c), dot4(s, s)};
-            wave_sum_n<2>(sqs);
+            wave_sum_to_sgpr<2>(sqs);
             const float sq = sqs[0], ss = sqs[1];
             float rn, kap, nc;
             unit_stats_bf(sq, eps_cos, eps_cos2, rn, kap, nc);
@@ -413,19 +413,24 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
         if (have_cur && has_spk) {
             GE2E_T2_LANE();
-            float eev[MR];      // the rows' squared norms, reduced together (independent DPP chains fill each other's wait states)
+            // The rows' squared norms are reduced together into scalars and dropped into LANE i of one register; the norm
+            // bookkeeping then runs ONCE (lane i = row i) instead of once per row on all 64 lanes, the row scalars leave
+            // in one LDS write, and each row's scale factor comes back as a scalar.
+            float eev[MR];
 #pragma unroll
             for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(rowv[i], rowv[i]) : 0.f;
-            wave_sum_n<MR>(eev);
+            wave_sum_to_sgpr<MR>(eev);
+            float ee_l = 0.f;
+            static_for<0, MR>([&](auto ic) { ee_l = lane_put<decltype(ic)::value>(ee_l, eev[decltype(ic)::value]); });
+            float rne_l, ke_l, ne_l;
+            unit_stats_bf(ee_l, eps_cos, eps_cos2, rne_l, ke_l, ne_l);
+            if (lv_ < M) *reinterpret_cast<float4*>(RS + (rbase + lv_) * 8) = make_float4(rne_l, ke_l, ee_l, ne_l);
+            const float rs_l = rne_l * kSplitScale;
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
-                    const float4 e = rowv[i];
-                    const float ee = eev[i];
-                    float rne, ke, ne;
-                    unit_stats_bf(ee, eps_cos, eps_cos2, rne, ke, ne);
-                    if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(e, rne * kSplitScale));
-                    if (lane == 0) *reinterpret_cast<float4*>(RS + (rbase + i) * 8) = make_float4(rne, ke, ee, ne);
+                    const float sc = lane_get(rs_l, i);
+                    if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(rowv[i], sc));
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
@@ -698,7 +703,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
                 if (lane == 0) add_agent(&fl->c3, 1u);
                 gsum = scale4(gsum, w * kSplitInv2);
-                const float coefc = wave_sum(dot4(gsum, cj_prev));
+                float cf[1] = {dot4(gsum, cj_prev)};
+                wave_sum_to_sgpr<1>(cf);
+                const float coefc = cf[0];
                 const float f = kap_prev * coefc, sc = rn_prev * inv_m;
                 if (dact)
                     *reinterpret_cast<float4*>(KJ + wid * D + d4) =

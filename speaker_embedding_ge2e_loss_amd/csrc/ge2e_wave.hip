@@ -19,8 +19,6 @@
 #include "ge2e_common.hpp"
 #include "ge2e_wave.hpp"
 
-#include <type_traits>
-
 namespace ge2e {
 
 namespace {
@@ -45,45 +43,6 @@ __device__ __forceinline__ void unit_stats_q(float sq, float eps_cos, float eps_
 __device__ __forceinline__ float rcp_q(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
     return r * (2.0f - x * r);
-}
-
-// Sum over the wave into an SGPR: four DPP steps inside each row of 16 lanes, two row broadcasts (lane 15 of a row into
-// the next row, lane 31 into rows 2 and 3) and one v_readlane of lane 63 -- 7 instructions a value against 12 for the
-// all-lanes form, and the result is a scalar operand.  K values stage by stage (see wave_sum_n).
-template <int K>
-__device__ __forceinline__ void wave_sum_to_sgpr(float (&v)[K]) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR1>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_XOR2>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_HALF_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += dpp_f<DPP_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = 0; k < K; ++k)   // row_bcast:15, rows 1 and 3
-        v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x142, 0xA, 0xF, false));
-#pragma unroll
-    for (int k = 0; k < K; ++k)   // row_bcast:31, rows 2 and 3
-        v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x143, 0xC, 0xF, false));
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
-}
-template <int R, int RMAX, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (R < RMAX) {
-        f(std::integral_constant<int, R>{});
-        static_for<R + 1, RMAX>(f);
-    }
-}
-template <int LANE>
-__device__ __forceinline__ float lane_put(float vec, float uniform) {   // vec[LANE] = uniform (a wave-uniform value)
-    const int u = __builtin_amdgcn_readfirstlane(__float_as_int(uniform));
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(u), "n"(LANE));
-    return vec;
-}
-__device__ __forceinline__ float lane_get(float vec, int lane_id) {                  // uniform = vec[lane_id]
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vec), lane_id));
 }
 
 // Three passes per batch.  (1) per row: its N + 2 dot products on the raw vectors, reduced to scalars and dropped into
