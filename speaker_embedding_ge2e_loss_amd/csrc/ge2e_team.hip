@@ -514,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 #undef T2_X_STORE
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
         }
+        GE2E_PROF(11);
         // ---- previous batch: scalars out ----------------------------------------------------------------------------
         if (have_prev) {
             if (id.member == 0 && wid == 0) {

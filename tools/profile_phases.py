@@ -31,7 +31,7 @@ PHASES = {
     "team": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
               "B requests, X, partials requested + barrier", "S softmax, G images + barrier",
               "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "end barrier",
-              "next rows requested", "GE"],
+              "next rows requested", "GE", "(B up to the end of the X loop; the B line is the rest: scalars out + barrier)"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
