@@ -1,8 +1,16 @@
-import torch, sys
-sys.path.insert(0, "/root/repo")
-import numpy as np
-from speaker_embedding_ge2e_loss_amd import functional as GF
-import bench
+#!/usr/bin/env python3
+"""Interleaved timing of the one-wave-per-batch kernel against the workgroup-per-batch kernel on the reference's own
+shapes (a few dozen rows), B = 1 and 4096, C ABI with reused buffers.  Usage (GPU box): python tools/small_shapes.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from speaker_embedding_ge2e_loss_amd import functional as GF  # noqa: E402
+
 dev = torch.device("cuda:0")
 for (N, M, D) in ((4, 5, 256), (2, 16, 256), (3, 8, 256), (2, 10, 256), (4, 4, 64), (6, 2, 128)):
     for B in (1, 4096):
