@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Soak: 300 launches per shape through AUTO, outputs NaN-poisoned before each, every launch bitwise equal to the first and
+the first checked against the fp64 oracle.  Usage (GPU box): python tools/soak_determinism.py"""
+import sys, numpy as np, torch
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import ge2e_oracle as orc
+from speaker_embedding_ge2e_loss_amd import functional as GF
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+bad = 0
+shapes = [(4096, 64, 10, 256), (150, 64, 10, 256), (9, 64, 10, 256), (33, 23, 7, 128), (40, 64, 10, 64), (17, 40, 16, 64), (300, 32, 16, 192), (700, 4, 5, 256), (90, 2, 16, 256)]
+for (B, N, M, D) in shapes:
+    E = orc.synth_embeddings((B, N, M, D), "unit", seed=B)
+    ref = orc.closed_form(E[:4], 10.0, -5.0)
+    e = torch.as_tensor(E, device=dev)
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    impl = GF.resolve_impl(B, N, M, D, "softmax", "auto")
+    out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None, dE=torch.empty_like(e), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
+    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", impl), dev)
+    first = None
+    reps = 60 if B > 1000 else 300
+    for k in range(reps):
+        out.dE.fill_(float("nan")); out.loss.fill_(float("nan"))
+        GF.loss_fwd_bwd(e, w, b, impl=impl, out=out, workspace=ws)
+        dE = out.dE.clone(); loss = out.loss.clone(); dw = out.dw.clone()
+        if first is None:
+            first = (dE, loss, dw)
+            d = dE[:4].cpu().numpy()
+            rel = np.linalg.norm(d - ref["dE"]) / np.linalg.norm(ref["dE"])
+            assert rel < 2e-5, (impl, rel)
+        else:
+            if not (torch.equal(dE, first[0]) and torch.equal(loss, first[1]) and torch.equal(dw, first[2])):
+                bad += 1
+                nb = int((dE != first[0]).flatten(1).any(1).sum())
+                print("MISMATCH", (B, N, M, D), impl, "rep", k, "batches differing", nb, flush=True)
+    print((B, N, M, D), impl, reps, "launches bitwise identical" if bad == 0 else f"bad so far {bad}", flush=True)
+print("TOTAL MISMATCHES", bad)
