@@ -53,7 +53,7 @@ extern "C" {
                                    GE2E_AUTO_NO_TEAM=1 is in the environment (a process sharing the GPU)      */
 
 #define GE2E_IMPL_WAVE 6        /* one WAVE per batch, the batch in registers, exact fp32, no workspace: the reference's
-                                   own shapes (a few dozen rows: N <= 2..6 depending on M in {2,3,4,5,6,8,10,16},
+                                   own shapes (up to 64 rows: N <= 3..12 depending on M in {2,3,4,5,6,8,10,16},
                                    D <= 256, D % 4 == 0)                                                        */
 
 #define GE2E_OK 0

@@ -44,7 +44,9 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
     switch (impl) {
         case GE2E_IMPL_AUTO:  // split-fp16 MFMA is fp32-grade (tests hold it to 2e-5) and the fastest
-            if (wave_supports(N, M, D)) return GE2E_IMPL_WAVE;   // a few dozen rows: one wave per batch, exact fp32
+            // a few dozen rows: one wave per batch, exact fp32 (31..64 rows: from a few hundred batches per launch on --
+            // 117-277 us against 262-408 us at B = 4096, but 30-44 us against 20-28 us for a single batch)
+            if (wave_supports(N, M, D) && (!wave_is_large(N, M) || B >= 384)) return GE2E_IMPL_WAVE;
             if (!(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D) && auto_may_team()) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;

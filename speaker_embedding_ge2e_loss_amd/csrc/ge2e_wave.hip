@@ -50,8 +50,8 @@ __device__ __forceinline__ float rcp_q(float x) {
 // coefficients of the row's gradient (the part that every lane used to compute redundantly per row: ~60 of a row's
 // ~350 instructions).  (3) per row: its coefficients read back as scalars (v_readlane), the vector part of the gradient.
 template <int M, int NX>
-__global__ __launch_bounds__(256, (NX * M > 30 ? 1 : 2)) void ge2e_wave_kernel(Problem p) {   // 32 rows: one workgroup per
-    static_assert(NX * M <= 64, "a row per lane in pass 2");                                     // CU, AGPRs instead of scratch
+__global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2e_wave_kernel(Problem p) {   // large: one wave per
+    static_assert(NX * M <= 64, "a row per lane in pass 2");                                                  // SIMD, AGPRs instead of scratch
     const int N_outer = p.N, D_outer = p.D;
     const int lane_outer = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
@@ -258,8 +258,10 @@ __global__ __launch_bounds__(256, (NX * M > 30 ? 1 : 2)) void ge2e_wave_kernel(P
     }
 }
 
-struct WaveShape { int M, NX; };
-constexpr WaveShape kShapes[] = {{2, 6}, {3, 5}, {4, 4}, {5, 4}, {6, 3}, {8, 3}, {10, 2}, {16, 2}};
+// Two instantiations per M: a small one (<= 30 rows: 2 waves per SIMD, registers only) and a large one (<= 64 rows, the
+// lane-per-row limit of pass 2: one wave per SIMD, the row registers spill into AGPRs).
+struct WaveShape { int M, NX, NXL; };
+constexpr WaveShape kShapes[] = {{2, 6, 12}, {3, 5, 10}, {4, 4, 10}, {5, 4, 8}, {6, 3, 8}, {8, 3, 8}, {10, 2, 6}, {16, 2, 3}};
 
 template <int M, int NX>
 hipError_t launch_mn(const Problem& p, hipStream_t stream) {
@@ -269,26 +271,38 @@ hipError_t launch_mn(const Problem& p, hipStream_t stream) {
     hipLaunchKernelGGL((ge2e_wave_kernel<M, NX>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
+template <int M, int NX, int NXL>
+hipError_t launch_m(const Problem& p, hipStream_t stream) {
+    return p.N <= NX ? launch_mn<M, NX>(p, stream) : launch_mn<M, NXL>(p, stream);
+}
 
 }  // namespace
 
 bool wave_supports(int N, int M, int D) {
     if (D < 4 || D > 256 || (D & 3) || N < 1 || M < 2) return false;
     for (const WaveShape& s : kShapes)
-        if (s.M == M) return N <= s.NX;
+        if (s.M == M) return N <= s.NXL;
+    return false;
+}
+
+// the large instantiations run one wave per SIMD and a single batch takes 30-45 us on its one wave: they pay from a few
+// hundred batches per launch on (the workgroup-per-batch kernel needs 27 us per 256 batches)
+bool wave_is_large(int N, int M) {
+    for (const WaveShape& s : kShapes)
+        if (s.M == M) return N > s.NX;
     return false;
 }
 
 hipError_t launch_wave(const Problem& p, hipStream_t stream) {
     switch (p.M) {
-        case 2: return launch_mn<2, 6>(p, stream);
-        case 3: return launch_mn<3, 5>(p, stream);
-        case 4: return launch_mn<4, 4>(p, stream);
-        case 5: return launch_mn<5, 4>(p, stream);
-        case 6: return launch_mn<6, 3>(p, stream);
-        case 8: return launch_mn<8, 3>(p, stream);
-        case 10: return launch_mn<10, 2>(p, stream);
-        case 16: return launch_mn<16, 2>(p, stream);
+        case 2: return launch_m<2, 6, 12>(p, stream);
+        case 3: return launch_m<3, 5, 10>(p, stream);
+        case 4: return launch_m<4, 4, 10>(p, stream);
+        case 5: return launch_m<5, 4, 8>(p, stream);
+        case 6: return launch_m<6, 3, 8>(p, stream);
+        case 8: return launch_m<8, 3, 8>(p, stream);
+        case 10: return launch_m<10, 2, 6>(p, stream);
+        case 16: return launch_m<16, 2, 3>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -5,6 +5,7 @@
 namespace ge2e {
 
 bool wave_supports(int N, int M, int D);
+bool wave_is_large(int N, int M);   // more than ~30 rows: the one-wave-per-SIMD instantiation
 hipError_t launch_wave(const Problem& p, hipStream_t stream);
 
 }  // namespace ge2e

@@ -126,7 +126,10 @@ def test_config5_large(GF):
                                    (2, 33, 9, 130), (1, 130, 3, 20), (4, 16, 16, 128), (1, 8, 40, 256),
                                    # one wave per batch: every instantiated M at its largest N, small and odd D, B > grid
                                    (5, 6, 2, 256), (3, 5, 3, 36), (9, 4, 4, 128), (2100, 4, 5, 256), (7, 3, 6, 64),
-                                   (3, 3, 8, 252), (4, 2, 10, 4), (6, 2, 16, 256), (2, 1, 16, 8)])
+                                   (3, 3, 8, 252), (4, 2, 10, 4), (6, 2, 16, 256), (2, 1, 16, 8),
+                                   # ... and its large (one wave per SIMD) instantiations at their largest N
+                                   (3, 12, 2, 64), (2, 10, 3, 128), (5, 10, 4, 256), (3, 8, 5, 256), (2, 8, 6, 100),
+                                   (3, 8, 8, 256), (2, 6, 10, 256), (4, 3, 16, 256), (2, 7, 5, 32)])
 @pytest.mark.parametrize("variant", ["softmax", "contrast"])
 def test_ragged_shapes(GF, shape, variant):
     """Odd sizes: N not a multiple of the wave, D not a multiple of 4, M = 2, N = 1."""

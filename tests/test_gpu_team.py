@@ -144,7 +144,9 @@ def test_auto_uses_team_for_few_batches(GF):
     assert GF.resolve_impl(1024, 64, 10, 256, "softmax", "auto") == "team"
     assert GF.resolve_impl(256, 64, 10, 256, "softmax", "auto") == "fused_split"   # one workgroup per CU, exactly one round
     assert GF.resolve_impl(1, 4, 5, 256, "softmax", "auto") == "wave"            # a few dozen rows: one wave per batch
-    assert GF.resolve_impl(1, 8, 5, 256, "softmax", "auto") == "fused_split"     # too few speakers for eight members
+    assert GF.resolve_impl(1, 8, 5, 256, "softmax", "auto") == "fused_split"     # 40 rows on one wave: only for many batches
+    assert GF.resolve_impl(1000, 8, 5, 256, "softmax", "auto") == "wave"
+    assert GF.resolve_impl(1, 12, 6, 256, "softmax", "auto") == "fused_split"    # too few speakers for eight members, too many rows for a wave
     with pytest.raises(RuntimeError):
         GF.resolve_impl(1, 64, 20, 256, "softmax", "team")                        # M > 16
 

@@ -12,7 +12,8 @@ import bench  # noqa: E402
 from speaker_embedding_ge2e_loss_amd import functional as GF  # noqa: E402
 
 dev = torch.device("cuda:0")
-for (N, M, D) in ((4, 5, 256), (2, 16, 256), (3, 8, 256), (2, 10, 256), (4, 4, 64), (6, 2, 128)):
+for (N, M, D) in ((4, 5, 256), (2, 16, 256), (3, 8, 256), (2, 10, 256), (4, 4, 64), (6, 2, 128),
+                  (8, 5, 256), (8, 8, 256), (6, 10, 256), (3, 16, 256), (10, 4, 256), (12, 2, 256), (10, 3, 128)):
     for B in (1, 4096):
         E = bench.synth(B, N, M, D, 1, dev)
         w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
