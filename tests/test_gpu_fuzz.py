@@ -1,0 +1,47 @@
+"""Seeded random shapes through impl="auto" (and every implementation that accepts the shape) against the fp64 closed
+form: whatever AUTO resolves to -- wave, team, fused_split, tiled, generic -- has to be right at shapes nobody tuned for."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ge2e_oracle as orc
+from test_gpu_parity import check, impls_for, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def GF():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from speaker_embedding_ge2e_loss_amd import functional
+    return functional
+
+
+def cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.integers(1, 71))
+        M = int(rng.integers(2, 17))
+        D = int(rng.choice([4, 20, 64, 96, 128, 192, 256, 257, 320]))
+        B = int(rng.integers(1, 600)) if N * M <= 64 and rng.random() < 0.5 else int(rng.integers(1, 12))
+        if B * N * M * D > 6e6:      # keep the fp64 oracle quick
+            continue
+        variant = "contrast" if (rng.random() < 0.3 and N > 1) else "softmax"
+        out.append((B, N, M, D, variant, float(rng.uniform(-4, 14)), float(rng.uniform(-6, 3))))
+    return out
+
+
+@pytest.mark.parametrize("case", cases(48, seed=2024), ids=lambda c: f"B{c[0]}_N{c[1]}_M{c[2]}_D{c[3]}_{c[4][0]}")
+def test_random_shapes(GF, case):
+    B, N, M, D, variant, w, b = case
+    E = orc.synth_embeddings((B, N, M, D), "raw" if (N + M) % 3 == 0 else "unit", seed=B * 7 + N)
+    ref = orc.closed_form(E, w, b, variant=variant)
+    seen = set()
+    for impl in impls_for(GF, B, N, M, D, variant):
+        resolved = GF.resolve_impl(B, N, M, D, variant, impl)
+        if resolved in seen and impl == "auto":
+            continue
+        seen.add(resolved)
+        check(run_hip(GF, E, w, b, variant, impl), ref, impl, f"{case}/{impl}->{resolved}")
