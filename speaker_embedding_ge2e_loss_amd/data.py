@@ -103,7 +103,8 @@ class GE2EBatchSampler:
                 st.buffer.data_ptr(), 1 if st.dtype == np.float64 else 0, base, base + 8 * N, base + 8 * N + 4 * N * M,
                 N, M, st.T, L, st.F, out.data_ptr(), torch.cuda.current_stream(st.device).cuda_stream)
         _lib.check(code, "ge2e_sample_batch")
-        out._ge2e_meta = dmeta  # keep the index buffer alive until the launch has consumed it (stream-ordered free)
+        # dmeta may go out of scope here: torch's allocator frees stream-ordered, and the launch above is already
+        # enqueued on the stream any re-use of the block would be ordered behind
         return out
 
     def loader(self, batch_size: int, shuffle: bool = True, generator: Optional[torch.Generator] = None) -> Iterator[torch.Tensor]:

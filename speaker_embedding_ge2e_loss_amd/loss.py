@@ -21,11 +21,17 @@ class _HPGeneral:
         self.small_err = small_err
 
 
+class _HPSection:
+    pass
+
+
 class HParams:
-    """Smallest object with the two fields the loss reads (strings/constants.py:31,34)."""
+    """Smallest object with the two fields the loss reads (strings/constants.py:31,34), plus an empty ``m_ge2e``
+    section for the callers that write into it (``calculate_ERR`` sets ``test_N`` / ``test_M``, s5:17-18)."""
 
     def __init__(self, device="cuda:0", small_err=1e-6):
         self.general = _HPGeneral(torch.device(device), small_err)
+        self.m_ge2e = _HPSection()
 
 
 class GE2ELoss(nn.Module):

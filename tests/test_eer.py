@@ -56,7 +56,6 @@ def test_calculate_err_end_to_end_on_gpu(capsys):
     from speaker_embedding_ge2e_loss_amd import HParams, functional as GF
     dev = torch.device("cuda:0")
     hp = HParams(device=dev)
-    hp.m_ge2e = type("m", (), {})()
     for name in CASES:
         E = torch.from_numpy(Z[name + ".E"])
         N, M, D = E.shape

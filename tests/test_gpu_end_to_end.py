@@ -46,6 +46,5 @@ def test_train_eval_pipeline_on_synthetic_speakers(capsys):
     # s5: EER on a test batch through the trained encoder (normalising encoder for evaluation: same weights)
     enc_eval = SpeakerEncoder(F, 24, 2, 16, normalize=True).to(dev)
     enc_eval.load_state_dict(enc.state_dict())
-    hp.m_ge2e = type("m", (), {})()
     res = calculate_ERR(enc_eval.eval(), hp, N=4, M=5, test_loader=[b.reshape(1, 20, 16, F) for b in test_batches[:1]])
     assert "EER :" in capsys.readouterr().out and set(res[0]) == {"EER", "thres", "FAR", "FRR"}
