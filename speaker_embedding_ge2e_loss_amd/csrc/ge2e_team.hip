@@ -276,15 +276,22 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const int kslot = 8 * id.member + wid;             // ... and the slot every wave is responsible for in A
     const int rbase = wid * M;                         // first row of that speaker in the images
 
-    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    // w and b are read once and kept as SCALAR bit patterns; every phase derives the constants it needs (w log2 e, 1 / M,
+    // ...) from an opaque copy of them (GE2E_T2_CONSTS).  Derived once at kernel scope they are uniform values in VGPRs
+    // for the whole kernel -- a dozen registers the allocator spills around the contractions.
+    const int w_bits = __builtin_amdgcn_readfirstlane(__float_as_int(p.w ? *p.w : p.w_imm));
+    const int b_bits = __builtin_amdgcn_readfirstlane(__float_as_int(p.b ? *p.b : p.b_imm));
     const float eps = p.eps, eps_cos = p.eps_cos;
-    const float eps_cos2 = eps_cos * eps_cos;
-    const float fM = (float)M, inv_m = 1.0f / fM, inv_m1 = 1.0f / (float)(M - 1);
+#define GE2E_T2_CONSTS()                                                                       \
+    int wb_ = w_bits, bb_ = b_bits, mc_ = M, le_ = __float_as_int(p.log_eps);                  \
+    asm volatile("" : "+s"(wb_), "+s"(bb_), "+s"(mc_), "+s"(le_));                             \
+    const float w = __int_as_float(wb_), bias = __int_as_float(bb_);                           \
+    const float eps_cos2 = eps_cos * eps_cos;                                                  \
+    const float fM = (float)mc_, inv_m = 1.0f / fM, inv_m1 = 1.0f / (float)(mc_ - 1);          \
+    (void)w; (void)bias; (void)eps_cos2; (void)fM; (void)inv_m; (void)inv_m1; (void)le_
     const bool want_grad = p.dE != nullptr;
     const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
-    // softmax in base 2: S2 = S log2(e)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    const float w2 = w * LOG2E, b2 = (w * eps + bias) * LOG2E, leps2 = p.log_eps * LOG2E;
 
     // rows of the ET images that never receive an embedding stay zero (they are contracted over in GC)
     for (int i = tid; i < RT * P / 8; i += 512) {
@@ -292,6 +299,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         reinterpret_cast<float4*>(ETl)[i] = zero4();
     }
     for (int i = tid; i < RT * 2; i += 512) reinterpret_cast<float4*>(RS)[i] = zero4();   // rows without an embedding
+    // ... and so do their rows of the G images (S writes only the rows of speakers that exist)
+    for (int i = tid; i < (int)(g_bytes / 16); i += 512) reinterpret_cast<float4*>(Gh)[i] = zero4();
     __syncthreads();
 
     float4 rowv[MR];            // this wave's rows of the batch about to start
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
         if (have_cur) {
             GE2E_T2_LANE();
+            GE2E_T2_CONSTS();
             float4 s = zero4();
 #pragma unroll
             for (int i = 0; i < MR; ++i)
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
         if (have_cur && has_spk) {
             GE2E_T2_LANE();
+            GE2E_T2_CONSTS();
             // The rows' squared norms are reduced together into scalars and dropped into LANE i of one register; the norm
             // bookkeeping then runs ONCE (lane i = row i) instead of once per row on all 64 lanes, the row scalars leave
             // in one LDS write, and each row's scale factor comes back as a scalar.
@@ -530,122 +541,158 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         GE2E_PROF(3);
 
         // ===== S(cur): leave-one-out statistics, S, loss, dL/dS -> G images, row coefficients =======================
+        // Wave s = speaker slot s (as in A): FOUR lanes per row, 16 similarities per lane, so the per-row algebra is
+        // replicated 4x instead of 16x, the row reductions are two quad DPP steps and one pass covers the speaker.
+        // Lane (rr = lane >> 2, qq = lane & 3) holds the slots (sb + j) & 63, j = 0..15, sb = (own slot & ~3) + 16 qq:
+        // aligned groups of four, and the own-speaker column is always one of values 0..3 of the lane qq == 0.
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        if (have_cur) {
+        if (have_cur && has_spk) {
             GE2E_T2_LANE();
-            const int c4 = 4 * l15;
-            const int nval = max(0, min(spm, N - (l15 >> 1) * spm));   // valid slots of the member this lane's columns belong to
-            const int kl = 4 * (l15 & 1);                              // slot index of column 0 inside its member
-            const bool kv0 = kl < nval, kv1 = kl + 1 < nval, kv2 = kl + 2 < nval, kv3 = kl + 3 < nval;
-            const int npass = CT_S ? RT / 4 : RBr * 4;
+            GE2E_T2_CONSTS();
+            const float w2 = w * LOG2E, b2 = (w * eps + bias) * LOG2E, leps2 = __int_as_float(le_) * LOG2E;   // softmax in base 2
+            const int rr = lv_ >> 2, qq = lv_ & 3;
+            const bool rv = rr < M;
+            const int r = rbase + min(rr, M - 1);
+            const int ko = kslot;                                   // own-speaker slot (wave-uniform)
+            const int sb = (ko & ~3) + 16 * qq;
+            const int jo = ko & 3;
+            const bool own_lane = qq == 0;
+            const bool all_valid = N == NC;
+            float x[16];
 #pragma unroll
-            for (int k = 0; k < (RBC * 4 + 7) / 8; ++k) {
-                const int pi = wid + 8 * k;
-                if (pi < npass) {
-                    const int r = 4 * pi + q;
-                    const bool rv = r < R_my;
-                    const int loc = min((r * L.mul_m) >> 16, 7);
-                    const int ko = 8 * id.member + loc;                    // own-speaker slot of this row
-                    const int dk = ko - c4;                                // own column = entry dk of this lane (if 0..3)
-                    const float4 x0 = *reinterpret_cast<const float4*>(XB0 + r * XP + c4);
-                    const float4 x1 = *reinterpret_cast<const float4*>(XB1 + r * XP + c4);
-                    const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
-                    const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee |e|
-                    const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
-                    const float rne = rs0.x, ke = rs0.y, ee = rs0.z, ne = rs0.w;        // all zero for rows without an embedding
-                    const float es = xo * cs.z * ne;                 // e . s_j
-                    const float eu = (es - ee) * inv_m1;
-                    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
-                    float rnu, ku, nu;
-                    unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
-                    const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
-                    const float sjj2 = fmaf(w2, cosd, b2);
-                    float c0[4], g[4];
-                    c0[0] = dk == 0 ? cosd : (x0.x + x1.x) * kSplitInv2;
-                    c0[1] = dk == 1 ? cosd : (x0.y + x1.y) * kSplitInv2;
-                    c0[2] = dk == 2 ? cosd : (x0.z + x1.z) * kSplitInv2;
-                    c0[3] = dk == 3 ? cosd : (x0.w + x1.w) * kSplitInv2;
-                    float per, ad0;
-                    if (!CONTRAST) {
-                        float sv[4];
-                        sv[0] = kv0 ? fmaf(w2, c0[0], b2) : -INFINITY;
-                        sv[1] = kv1 ? fmaf(w2, c0[1], b2) : -INFINITY;
-                        sv[2] = kv2 ? fmaf(w2, c0[2], b2) : -INFINITY;
-                        sv[3] = kv3 ? fmaf(w2, c0[3], b2) : -INFINITY;
-                        float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-                        mx = fmaxf(row16_max(mx), leps2);
-                        float zoff = 0.f;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int s4 = (sb + 4 * jj) & (NC - 1);
+                const float4 a = *reinterpret_cast<const float4*>(XB0 + r * XP + s4);
+                const float4 b = *reinterpret_cast<const float4*>(XB1 + r * XP + s4);
+                x[4 * jj + 0] = a.x + b.x; x[4 * jj + 1] = a.y + b.y; x[4 * jj + 2] = a.z + b.z; x[4 * jj + 3] = a.w + b.w;
+            }
+            const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
+            const float4 rs0 = *reinterpret_cast<const float4*>(RS + r * 8);    // rne ke ee |e|
+            const float4 cs = *reinterpret_cast<const float4*>(CST + ko * 4);   // rn kap |s| |s|^2
+            const float rne = rs0.x, ke = rs0.y, ee = rs0.z, ne = rs0.w;
+            const float es = xo * cs.z * ne;                 // e . s_j
+            const float eu = (es - ee) * inv_m1;
+            const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+            float rnu, ku, nu;
+            unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
+            const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+            const float sjj2 = fmaf(w2, cosd, b2);
+            const float w2s = w2 * kSplitInv2;               // S2 = w2s x + b2 on the raw accumulator sums
+            // validity of this lane's slots (members with fewer than spm speakers): slot = 8 m' + loc valid iff loc < nval(m')
+            auto vld = [&](int j) {
+                const int s = (sb + j) & (NC - 1);
+                return all_valid || (s & 7) < max(0, min(spm, N - (s >> 3) * spm));
+            };
+            bool ownj[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            g[e] = __builtin_amdgcn_exp2f(sv[e] - mx);   // 2^-inf = 0 for unused slots
-                            zoff += dk == e ? 0.f : g[e];
-                        }
-                        zoff = row16_sum(zoff) + __builtin_amdgcn_exp2f(leps2 - mx);
-                        const float z = zoff + __builtin_amdgcn_exp2f(sjj2 - mx);
-                        per = LN2 * ((mx - sjj2) + __builtin_amdgcn_logf(z));
-                        const float rz = rcp_nr(z);
-                        ad0 = rv ? -zoff * rz : 0.f;                 // dL/dS on the own-speaker column: -(1 - p_jj) = -z_off / z
-                        const float rzv = rv ? rz : 0.f;
+            for (int j = 0; j < 4; ++j) ownj[j] = own_lane && jo == j;
+            float per, ad0, coefsum, db_row;
+            float gv[16];
+            if (!CONTRAST) {
+                // the row maximum over the OTHER speakers' columns (the own column enters with its leave-one-out value)
+                float xm0 = ownj[0] ? x[1] : x[0], xm1 = ownj[1] ? x[0] : x[1], xm2 = ownj[2] ? x[3] : x[2], xm3 = ownj[3] ? x[2] : x[3];
+                float xm;
+                if (w2 >= 0.f) {
+                    xm = fmaxf(fmaxf(xm0, xm1), fmaxf(xm2, xm3));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : g[e] * rzv;
-                    } else {
-                        float best = -INFINITY; int besti = 0x7fffffff;
-                        const bool kv[4] = {kv0, kv1, kv2, kv3};
+                    for (int j = 4; j < 16; j += 2) xm = fmaxf(fmaxf(x[j], x[j + 1]), xm);
+                } else {
+                    xm = fminf(fminf(xm0, xm1), fminf(xm2, xm3));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float sve = kv[e] ? fmaf(w2, c0[e], b2) : -INFINITY;
-                            if (dk != e && sve > best) { best = sve; besti = c4 + e; }
-                        }
-                        row16_argmax(best, besti);
-                        const float pos = rcp_nr(1.0f + __builtin_amdgcn_exp2f(-sjj2));
-                        const float neg = (N > 1) ? rcp_nr(1.0f + __builtin_amdgcn_exp2f(-best)) : 0.0f;
-                        per = 1.0f - pos + neg;
-                        ad0 = rv ? -pos * (1.0f - pos) : 0.f;
-                        const float gn = rv ? neg * (1.0f - neg) : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] = dk == e ? ad0 : ((c4 + e == besti && kv[e]) ? gn : 0.f);
-                    }
-                    float coef = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dw_acc = fmaf(g[e], c0[e] + eps, dw_acc);
-                        db_acc += g[e];
-                        coef = fmaf(g[e], c0[e], coef);       // (dL/d e-hat) . e-hat / w, own-speaker term included
-                    }
-                    if (rv && l15 == 0) {
-                        loss_acc += per;
-                        if (p.per) p.per[(size_t)bi * NM + j0 * M + r] = per;
-                    }
-                    if (want_grad) {
-                        coef = w * row16_sum(coef);
-                        // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
-                        // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
-                        // of s_j (o, in units of ra) without dividing by w
-                        const float ad = w * ad0;
-                        const float rho = rnu * inv_m1;
-                        const float t1 = ku * cosd * rho;                        // kappa_u cos rho
-                        const float c2_0 = rho * ad0 * (rne + t1);               // c2 / w
-                        const float c1 = -ke * coef * rne - ad * rho - w * c2_0 * ne;
-                        const float alpha = ad * rnu * (1.0f + t1 * ne);
-                        const float beta = -ad * rnu * t1;
-                        const float o = c2_0 * cs.z * ne;
-                        // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
-                        // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
-                        const float lam = cs.x * inv_m * w;
-                        if (l15 == 0)
-                            *reinterpret_cast<float4*>(RS + r * 8 + 4) =
-                                make_float4(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
-                                            c1 * kSplitInv,                                 // c1: of the e-hat image value (2^8)
-                                            (alpha * inv_m1 - lam * o) * kSplitInv,         // c3'
-                                            beta * inv_m1 * cs.z + lam * cs.y * o * xo);    // c4' (of c-hat_j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[e] = (dk == e ? o : g[e]) * kSplitScale;
-                        put_split4(Gh, Gl, r * GP + c4, make_float4(g[0], g[1], g[2], g[3]));
-                    }
+                    for (int j = 4; j < 16; j += 2) xm = fminf(fminf(x[j], x[j + 1]), xm);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaved passes cost more registers than there are
+                float mx = quad_max(fmaf(w2s, xm, b2));
+                mx = fmaxf(fmaxf(mx, sjj2), leps2);
+                const float t = b2 - mx;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gv[j] = __builtin_amdgcn_exp2f(fmaf(w2s, x[j], t));
+                if (!all_valid) {   // members with fewer than spm speakers: their empty slots do not count
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) gv[j] = vld(j) ? gv[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = ownj[j] ? 0.f : gv[j];
+                float zl = 0.f, al = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    zl += gv[j];
+                    al = fmaf(gv[j], x[j], al);
+                }
+                const float zp = quad_sum(zl);                // sum over the other speakers, shifted
+                const float ap = quad_sum(al);
+                const float zoff = zp + __builtin_amdgcn_exp2f(leps2 - mx);
+                const float z = zoff + __builtin_amdgcn_exp2f(sjj2 - mx);
+                per = LN2 * ((mx - sjj2) + __builtin_amdgcn_logf(z));
+                const float rz = rcp_nr(z);
+                ad0 = rv ? -zoff * rz : 0.f;                  // dL/dS on the own-speaker column: -(1 - p_jj) = -z_off / z
+                const float rzv = rv ? rz : 0.f;
+                coefsum = fmaf(ap * kSplitInv2, rzv, ad0 * cosd);     // sum_k dL/dS_k c0_k
+                db_row = fmaf(zp, rzv, ad0);
+                const float gs = rzv * kSplitScale;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gv[j] *= gs;
+            } else {
+                float best = -INFINITY, bx = 0.f; int besti = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int s = (sb + j) & (NC - 1);
+                    const bool ok = vld(j) && !(j < 4 && ownj[j & 3]);
+                    const float sve = ok ? fmaf(w2s, x[j], b2) : -INFINITY;
+                    if (ok && (sve > best || (sve == best && s < besti))) { best = sve; besti = s; bx = x[j]; }
+                }
+                const int loci = besti;
+                quad_argmax(best, besti);
+                bx = quad_sum(loci == besti && besti != 0x7fffffff ? bx : 0.f);
+                const float pos = rcp_nr(1.0f + __builtin_amdgcn_exp2f(-sjj2));
+                const float neg = (N > 1) ? rcp_nr(1.0f + __builtin_amdgcn_exp2f(-best)) : 0.0f;
+                per = 1.0f - pos + neg;
+                ad0 = rv ? -pos * (1.0f - pos) : 0.f;
+                const float gn = rv ? neg * (1.0f - neg) : 0.f;
+                coefsum = fmaf(gn, bx * kSplitInv2, ad0 * cosd);
+                db_row = gn + ad0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gv[j] = (((sb + j) & (NC - 1)) == besti && vld(j)) ? gn * kSplitScale : 0.f;
+            }
+            if (rv && own_lane) {
+                loss_acc = per;
+                dw_acc = fmaf(eps, db_row, coefsum);
+                db_acc = db_row;
+                if (p.per) p.per[(size_t)bi * NM + j0 * M + rbase + rr] = per;
+            }
+            if (want_grad) {
+                const float coef = w * coefsum;                  // (dL/d e-hat) . e-hat, own-speaker term included
+                // dE_r = ra acc + c1 e-hat + c2 s_j + KJ_j   (ge2e_fused_f32.hip header for the algebra); everything
+                // that multiplies the own-column gradient is linear in w, so the G image can carry the coefficient
+                // of s_j (o, in units of ra) without dividing by w
+                const float ad = w * ad0;
+                const float rho = rnu * inv_m1;
+                const float t1 = ku * cosd * rho;                        // kappa_u cos rho
+                const float c2_0 = rho * ad0 * (rne + t1);               // c2 / w
+                const float c1 = -ke * coef * rne - ad * rho - w * c2_0 * ne;
+                const float alpha = ad * rnu * (1.0f + t1 * ne);
+                const float beta = -ad * rnu * t1;
+                const float o = c2_0 * cs.z * ne;
+                // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
+                // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
+                const float lam = cs.x * inv_m * w;
+                if (rv && own_lane)
+                    *reinterpret_cast<float4*>(RS + r * 8 + 4) =
+                        make_float4(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
+                                    c1 * kSplitInv,                                 // c1: of the e-hat image value (2^8)
+                                    (alpha * inv_m1 - lam * o) * kSplitInv,         // c3'
+                                    beta * inv_m1 * cs.z + lam * cs.y * o * xo);    // c4' (of c-hat_j)
+                const float og = o * kSplitScale;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = ownj[j] ? og : gv[j];
+                if (rv) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        put_split4(Gh, Gl, r * GP + ((sb + 4 * jj) & (NC - 1)),
+                                   make_float4(gv[4 * jj], gv[4 * jj + 1], gv[4 * jj + 2], gv[4 * jj + 3]));
+                }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
         loss_acc = wave_sum(loss_acc);
         dw_acc = wave_sum(dw_acc);
@@ -655,27 +702,27 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         GE2E_PROF(4);
 
         // ===== F: member scalars out; KJ_j of prev (its partial gradients have arrived) and KJP'_j of cur ===========
-        // first the requests whose answers are needed a phase or more from now: GE's centroid fragments (k-group form)
-        // and the next batch's rows (in flight under GC / GE and the next A1)
-        {
-            GE2E_T2_LANE();
-            if (have_prev && want_grad && has_spk) {      // my speaker's eight partial gradients (they land under KJP below)
-                const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;
-#pragma unroll
-                for (int mm = 1; mm < TEAM; ++mm)
-                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
-            }
-        }
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
             bstore4(rsX, XO.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
+        // Straight-line on purpose: in the first iteration (no prev) the loads go out of bounds and read zeros, in the
+        // last one (no cur) KJP' is computed from stale images and dropped; only the counter add and the KJ store are
+        // conditional.  (With the loads and the sums under separate `if (have_prev)`s hipcc split the loop body on that
+        // flag, put the loads a region away from their uses and parked them in scratch: a full wait per load.)
         if (want_grad && has_spk) {
             GE2E_T2_LANE();
+            GE2E_T2_CONSTS();
+            {   // my speaker's partial gradients from the seven other members (they land under KJP' below)
+                const unsigned vrow = (dact && have_prev) ? (unsigned)d4 * 4u : OOB;
+#pragma unroll
+                for (int mm = 1; mm < TEAM; ++mm)
+                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
+            }
             const float4 kjp_prev = kjp;
-            if (have_cur) {   // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
+            {   // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
                 kjp = zero4();
                 const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
                 const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
@@ -694,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
                 if (!dact) kjp = zero4();
             }
-            if (have_prev) {
+            {
                 // fixed order (own slice first, then members member+1 .. member+7 mod 8): deterministic
                 float4 gsum = ownp;
 #pragma unroll
@@ -702,13 +749,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 // every partial of this speaker has been read (the sums above waited for them; nothing of this wave's
                 // is behind them that the counted wait would have to skip): the single gC buffer may be rewritten
                 asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
-                if (lane == 0) add_agent(&fl->c3, 1u);
+                if (lane == 0 && have_prev) add_agent(&fl->c3, 1u);
                 gsum = scale4(gsum, w * kSplitInv2);
                 float cf[1] = {dot4(gsum, cj_prev)};
                 wave_sum_to_sgpr<1>(cf);
                 const float coefc = cf[0];
                 const float f = kap_prev * coefc, sc = rn_prev * inv_m;
-                if (dact)
+                if (dact && have_prev)
                     *reinterpret_cast<float4*>(KJ + wid * D + d4) =
                         make_float4((gsum.x - f * cj_prev.x) * sc + kjp_prev.x, (gsum.y - f * cj_prev.y) * sc + kjp_prev.y,
                                     (gsum.z - f * cj_prev.z) * sc + kjp_prev.z, (gsum.w - f * cj_prev.w) * sc + kjp_prev.w);
@@ -760,22 +807,21 @@ _Pragma("unroll")                                                               
         if (!have_cur) break;
 
         if (want_grad) {
-            {   // GE's centroid fragments (k-group form): requested here, they land under GC
-                GE2E_T2_LANE();
-                {
-#pragma unroll
-                    for (int i = 0; i < NTI; ++i) {
-                        const int dt = T2_DT(i);
-                        const bool on = dt < NT;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u;
-                            ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);
-                            ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);
-                        }
-                    }
-                }
-            }
+            // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
+            // dead (requested before it they cost 32 more registers under the accumulators and the allocator spilled
+            // them); the answers land under the read-done wait and the partial-gradient stores
+#define T2_GA_LOAD()                                                                                                      \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NTI; ++i) {                                                                 \
+            const int dt = T2_DT(i);                                                                                      \
+            const bool on = dt < NT;                                                                                      \
+            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
+                const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u; \
+                ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);                                                    \
+                ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);                                \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
             // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
             {
                 GE2E_T2_LANE();
@@ -807,6 +853,7 @@ _Pragma("unroll")                                                               
                         }
                     }
 #undef T2_GC_LOAD
+                    T2_GA_LOAD();
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -844,11 +891,13 @@ _Pragma("unroll")                                                               
 #undef T2_OWN
                         }
                     }
+                } else {
+                    T2_GA_LOAD();
                 }
             }
+#undef T2_GA_LOAD
             GE2E_PROF(7);
         }
-        GE2E_T2_LOAD_ROWS(bi + id.nct);   // the next batch's rows: in flight under GE and the next A1
         GE2E_PROF(9);
         if (want_grad) {
             // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
@@ -900,6 +949,11 @@ _Pragma("unroll")                                                               
             }
         }
         GE2E_PROF(10);
+        // The next batch's rows are requested only now, after GE: requested before it (round 2) their 40 registers sat under
+        // GE's fragments and accumulators, the kernel's register peak (237 against 205 now), and the end barrier and the
+        // next A1's first instructions cover about as much of the HBM round trip as GE did (+4 % measured).  An L2
+        // prefetch a phase ahead (one dword per 64 bytes through the LDS-DMA path) cost 6 %: 64 lines per instruction.
+        GE2E_T2_LOAD_ROWS(bi + id.nct);
         // the next iteration's A rewrites the ET images and the stage inside the X block
         __syncthreads();
         GE2E_PROF(8);
@@ -908,6 +962,7 @@ _Pragma("unroll")                                                               
     GE2E_PROF_FLUSH(12)
 #undef GE2E_T2_LOAD_ROWS
 #undef GE2E_T2_LANE
+#undef GE2E_T2_CONSTS
 }
 
 // ---------------------------------------------------------------------------------------------
