@@ -176,7 +176,9 @@ constexpr unsigned team_xb_bytes(int rt, int D) {
     if (xb < 2u * 8 * (D + STGPAD) * 2) xb = 2u * 8 * (D + STGPAD) * 2;   // the centroid for its k-group form: [hi, lo][8][D + 32] halfs
     return xb;
 }
-constexpr unsigned team_g_bytes(int rt) { return 2u * rt * GP * 2; }
+constexpr unsigned team_g_bytes(int rt, int D) {     // the G images; between two batches the region holds the KJ rows [8][D]
+    return 2u * rt * GP * 2 > 8u * D * 4 ? 2u * rt * GP * 2 : 8u * D * 4;
+}
 
 TeamKWs team_layout(int N, int M, int D) {
     TeamKWs L{};
@@ -187,7 +189,7 @@ TeamKWs team_layout(int N, int M, int D) {
     const int P = D + 16;
     const size_t et = (size_t)2 * L.rt * P * 2;
     const size_t xb = team_xb_bytes(L.rt, D);
-    const size_t g = team_g_bytes(L.rt);
+    const size_t g = team_g_bytes(L.rt, D);
     L.xb_bytes = (unsigned)xb;
     L.g_bytes = (unsigned)g;
     L.lds_bytes = et + 2 * xb + g + (size_t)(L.rt * 8 + NC * 4 + 32 + 16) * sizeof(float);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
     // compile-time shape: every LDS offset is an immediate (fewer scalars to keep -- the kernel spills SGPRs)
     const unsigned xb_bytes = RBT ? team_xb_bytes(16 * RBT, D) : L.xb_bytes;
-    const unsigned g_bytes = RBT ? team_g_bytes(16 * RBT) : L.g_bytes;
+    const unsigned g_bytes = RBT ? team_g_bytes(16 * RBT, D) : L.g_bytes;
     float* const XB1 = XB0 + xb_bytes / 4;
     _Float16* const Gh = reinterpret_cast<_Float16*>(XB1 + xb_bytes / 4);
     _Float16* const Gl = Gh + RT * GP;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     float* const CST = RS + RT * 8;                                // [64][4]  1/|c|, kappa, |s|, |s|^2 of every slot
     float* const RED = CST + NC * 4;                               // [32]
     int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
-    float* const KJ = XB0;                                         // F: KJ_j rows [8][D] (X has been consumed by then)
+    float* const KJ = reinterpret_cast<float*>(Gh);                // F1 -> dE: KJ_j rows [8][D]; the G images are dead from GE(prev) to S(cur)
     float* const OWNP = XB0 + 8 * D;                               // GC -> next A1: own slots of this member's partial gC [8][D]
     _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: centroid stage [hi, lo][8 slots][D + STGPAD]
     constexpr int SP = D + STGPAD;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     float4 rowv[MR];            // this wave's rows of the batch about to start
     float4 held[NTI][RBC];      // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..   (GE -> next iteration)
     float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                      (F -> next F)
-    float4 ownp = zero4();      // this member's own partial gC of this wave's speaker, 4 columns (GC -> LDS -> next F)
+    h8 ga[NTI][2][2] = {};      // GE's centroid fragments: columns 16 dt + l15, slots 32 s2 + 8 q .. (k-group form; GC -> next GE)
     float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
     float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
 #pragma unroll
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const bool dact = d4 < D;                                           \
     (void)l15; (void)q; (void)d4; (void)dact
 
-    GE2E_PROF_DECL(12)
+    GE2E_PROF_DECL(13)
     GE2E_T2_LOAD_ROWS(id.team);
     const TeamId id_outer = id;
     int wslot = 0;
@@ -363,11 +365,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
                                                        want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
         cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
-        if (have_prev && want_grad) {   // the own slice never travels through L2 (64 KB per batch and team less to write back)
-            GE2E_T2_LANE();
-            ownp = *reinterpret_cast<const float4*>(OWNP + wid * D + min(d4, D - 4));
-        }
-
         // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
         if (have_cur) {
             GE2E_T2_LANE();
@@ -420,6 +417,97 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         }
         GE2E_PROF(0);
 
+        if (want_grad && have_prev) {
+            // ===== GE(prev): gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers until dE ==========
+            // The G fragments of the next row block and this block's epilogue operands are requested before the MFMAs.
+            {
+                GE2E_T2_LANE();
+                int rbg = RB;
+                asm volatile("" : "+s"(rbg));
+                h8 gb[2][2][2];             // [set][s2][hi, lo]: G rows 16 rb + l15, slots 32 s2 + 8 q ..
+#define T2_GE_LOAD(RB_)                                                                                      \
+    do {                                                                                                     \
+        const int r_ = 16 * (RB_) + l15;                                                                     \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
+            gb[(RB_) & 1][s2][0] = frag_row(Gh + r_ * GP + 32 * s2 + 8 * q);                                 \
+            gb[(RB_) & 1][s2][1] = frag_row(Gl + r_ * GP + 32 * s2 + 8 * q);                                 \
+        }                                                                                                    \
+    } while (0)
+                T2_GE_LOAD(0);
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb) {
+                    if (rb < rbg) {
+                        const int r = 16 * rb + l15;
+                        if (rb > 0) T2_GE_LOAD(rb);
+                        const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
+                        h4 eh[NTI], el[NTI];
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            const int eo = r * P + min(16 * T2_DT(i), D - 16) + 4 * q;
+                            eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
+                            el[i] = *reinterpret_cast<const h4*>(ETl + eo);
+                        }
+                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i) {
+                            f32x4 acc = acc_zero4();
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2)
+                                mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
+                            held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
+                                                      fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
+                                                      fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
+                                                      fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
+                        }
+                        if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
+                        __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
+                    }
+                }
+#undef T2_GE_LOAD
+            }
+        }
+        GE2E_PROF(10);
+
+        // ===== W: both hand-offs (signalled by every member at the same point) ======================================
+        {
+            int* const wsh = SH + 4 + (wslot & 3);
+            ++wslot;
+            if (tid == 0) {
+                bool ok = true;
+                if (have_cur) ok = spin_until(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl);
+                if (ok && have_prev) ok = spin_until(&fl->c2, (unsigned)(TEAM * seq), ctl);
+                *wsh = ok ? 1 : 0;
+            }
+            __syncthreads();                 // also: every wave's ET rows and row scalars are written
+            if (*wsh == 0) { failed = true; break; }
+        }
+        GE2E_PROF(2);
+
+        // ===== B: centroid fragments, previous batch's partial gradients and scalars -> registers ===================
+        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
+        float4 part[TEAM - 1];  // the seven other members' partials of my speaker (prev), in rotated member order
+        float4 cstv, scv;
+        {   // every load unconditional (out-of-bounds offsets read zeros): a load under an `if` is a phi at the join, and
+            // hipcc resolves it with s_waitcnt vmcnt(0) -- a full L2 round trip in front of A2
+            GE2E_T2_LANE();
+            const unsigned oa = have_cur ? XO.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u : OOB;
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) {
+                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
+                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
+            }
+            cstv = bload4<AUX_L2>(rsX, have_cur && tid < NC ? XO.cst[buf] + (unsigned)tid * 16u : OOB, 0);
+            scv = bload4<AUX_L2>(rsX, have_prev && id.member == 0 && tid < TEAM ? XO.sc[pbuf] + (unsigned)tid * 16u : OOB, 0);
+            if (want_grad) {   // my speaker's partial gradients of prev (first iteration: out of bounds, zeros); used in F1
+                const unsigned vrow = (dact && have_prev && has_spk) ? (unsigned)d4 * 4u : OOB;
+#pragma unroll
+                for (int mm = 1; mm < TEAM; ++mm)
+                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
+            }
+        }
+        GE2E_PROF(9);
+
+
         // ===== A2(cur): own rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile) ========================
         if (have_cur && has_spk) {
             GE2E_T2_LANE();
@@ -446,43 +534,93 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
         }
+        // The next batch's rows are requested as soon as this batch's have become images: a whole iteration ahead of their
+        // first use (A1 at the top of the next one), and BEHIND the requests above in the memory queue, which retires in
+        // order: nothing that is waited for before the next A1 queues behind this HBM round trip.
+        GE2E_T2_LOAD_ROWS(bi + id.nct);
         GE2E_PROF(1);
 
-        // ===== W: both hand-offs (signalled by every member at the same point) ======================================
-        {
-            int* const wsh = SH + 4 + (wslot & 3);
-            ++wslot;
-            if (tid == 0) {
-                bool ok = true;
-                if (have_cur) ok = spin_until(&fl->c1, (unsigned)(TEAM * (seq + 1)), ctl);
-                if (ok && have_prev) ok = spin_until(&fl->c2, (unsigned)(TEAM * seq), ctl);
-                *wsh = ok ? 1 : 0;
-            }
-            __syncthreads();                 // also: every wave's ET rows and row scalars are written
-            if (*wsh == 0) { failed = true; break; }
-        }
-        GE2E_PROF(2);
-
-        // ===== B: centroid fragments, previous batch's partial gradients and scalars -> registers ===================
-        h8 xa[NCH][2];          // X: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..      (row-major form)
-        h8 ga[NTI][2][2];       // GE: columns 16 dt + l15, slots 32 s2 + 8 q ..           (k-group form)
-        float4 part[TEAM - 1];  // the other members' partials of my speaker, in rotated member order (own first, from LDS)
-        float4 cstv = zero4(), scv = zero4();
-        {
+        // ===== F1: KJ_j of prev from the partial gradients (requested before A2, in registers by now) -> LDS ========
+        // Straight-line on purpose: in the first iteration (no prev) the loads went out of bounds and read zeros; only the
+        // counter add and the KJ store are conditional.  (With the loads and the sums under separate `if (have_prev)`s
+        // hipcc split the loop body on that flag, put the loads a region away from their uses and parked them in scratch.)
+        if (want_grad && has_spk) {
             GE2E_T2_LANE();
-            if (have_cur) {
-                const unsigned oa = XO.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u;
+            GE2E_T2_CONSTS();
+            // fixed order (own slice first -- it never travels through L2 --, then members member+1 .. member+7 mod 8)
+            float4 gsum = *reinterpret_cast<const float4*>(OWNP + wid * D + min(d4, D - 4));
+            if (!have_prev) gsum = zero4();
 #pragma unroll
-                for (int s = 0; s < NCH; ++s) {
-                    xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
-                    xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
+            for (int m = 0; m < TEAM - 1; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
+            // every partial of this speaker has been read (the sums above waited for them): the single gC buffer may be
+            // rewritten
+            asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
+            if (lane == 0 && have_prev) add_agent(&fl->c3, 1u);
+            gsum = scale4(gsum, w * kSplitInv2);
+            float cf[1] = {dot4(gsum, cj_prev)};
+            wave_sum_to_sgpr<1>(cf);
+            const float coefc = cf[0];
+            const float f = kap_prev * coefc, sc = rn_prev * inv_m;
+            if (dact && have_prev)
+                *reinterpret_cast<float4*>(KJ + wid * D + d4) =
+                    make_float4((gsum.x - f * cj_prev.x) * sc + kjp.x, (gsum.y - f * cj_prev.y) * sc + kjp.y,
+                                (gsum.z - f * cj_prev.z) * sc + kjp.z, (gsum.w - f * cj_prev.w) * sc + kjp.w);
+        }
+        __syncthreads();                 // KJ rows; every wave's ET rows and row scalars of cur are written
+        GE2E_PROF(5);
+
+        // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ================
+        // The sums are formed IN the held registers and stored from there: nothing writes those registers again before
+        // the next GE.  (A store's data registers must not be reused soon after it: with the memory pipe backed up a
+        // queued store reads its data late.)  All KJ reads first, then the sums and stores: written as one loop hipcc
+        // recycles ONE temporary and serialises ten LDS round trips per wave (2.8 k cycles for the older wave of a SIMD,
+        // 6 k for the younger).  Tried and dropped: the stores under GC's MFMAs -- the wave blocks at store issue and
+        // GC went from 6 k to 10 k cycles (-7 % overall).
+#define T2_DE_STORES()                                                                                                     \
+    do {                                                                                                                   \
+            GE2E_T2_LANE();                                                                                                \
+_Pragma("unroll")                                                                                                          \
+            for (int i = 0; i < NTI; ++i) {                                                                                \
+                float4 kjv[RBC];                                                                                           \
+_Pragma("unroll")                                                                                                          \
+                for (int rb = 0; rb < RBC; ++rb)                                                                           \
+                    if (CT_DE || rb < RBr) {                                                                               \
+                                                                                                                           \
+                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
+                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
+                        kjv[rb] = *reinterpret_cast<const float4*>(KJ + min((r * L.mul_m) >> 16, 7) * D + min(c, D - 4));  \
+                    }                                                                                                      \
+_Pragma("unroll")                                                                                                          \
+                for (int rb = 0; rb < RBC; ++rb)                                                                           \
+                    if (CT_DE || rb < RBr) {                                                                               \
+                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
+                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
+                        const bool ok = r < R_my && T2_DT(i) < NT;                                                         \
+                        held[i][rb].x += kjv[rb].x; held[i][rb].y += kjv[rb].y;                                            \
+                        held[i][rb].z += kjv[rb].z; held[i][rb].w += kjv[rb].w;                                            \
+                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + c) * 4u : OOB, held[i][rb]);      \
+                    }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+    } while (0)
+        // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
+        // stores wait to issue.  Tried and dropped: the stores under GC's MFMAs (GC 6 k -> 10 k cycles, -7 % overall);
+        // the younger wave of every SIMD running GC first and storing after it (its GC + stores take the same 11 k).
+        if (want_grad && have_prev) T2_DE_STORES();
+#undef T2_DE_STORES
+        GE2E_PROF(6);
+        // ---- previous batch: scalars out ----------------------------------------------------------------------------
+        if (have_prev) {
+            if (id.member == 0 && wid == 0) {
+                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+                if (lane == 0) {
+                    if (p.loss) p.loss[bi - id.nct] = l;
+                    if (p.dw) p.dw[bi - id.nct] = a;
+                    if (p.db) p.db[bi - id.nct] = c;
                 }
-                if (tid < NC) cstv = bload4<AUX_L2>(rsX, XO.cst[buf] + (unsigned)tid * 16u, 0);
-            }
-            if (have_prev) {
-                if (id.member == 0 && tid < TEAM) scv = bload4<AUX_L2>(rsX, XO.sc[pbuf] + (unsigned)tid * 16u, 0);
             }
         }
+        if (!have_cur) break;
 
         // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
         if (have_cur) {
@@ -526,17 +664,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
         }
         GE2E_PROF(11);
-        // ---- previous batch: scalars out ----------------------------------------------------------------------------
-        if (have_prev) {
-            if (id.member == 0 && wid == 0) {
-                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
-                if (lane == 0) {
-                    if (p.loss) p.loss[bi - id.nct] = l;
-                    if (p.dw) p.dw[bi - id.nct] = a;
-                    if (p.db) p.db[bi - id.nct] = c;
-                }
-            }
-        }
         __syncthreads();
         GE2E_PROF(3);
 
@@ -546,6 +673,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // Lane (rr = lane >> 2, qq = lane & 3) holds the slots (sb + j) & 63, j = 0..15, sb = (own slot & ~3) + 16 qq:
         // aligned groups of four, and the own-speaker column is always one of values 0..3 of the lane qq == 0.
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        if (have_cur && want_grad && R_my < RT) {   // image rows without a speaker: the KJ rows of F1 have been lying there
+            for (int i = tid; i < (RT - R_my) * GP / 8; i += 512) {
+                reinterpret_cast<float4*>(Gh + R_my * GP)[i] = zero4();
+                reinterpret_cast<float4*>(Gl + R_my * GP)[i] = zero4();
+            }
+        }
         if (have_cur && has_spk) {
             GE2E_T2_LANE();
             GE2E_T2_CONSTS();
@@ -701,110 +834,35 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         __syncthreads();
         GE2E_PROF(4);
 
-        // ===== F: member scalars out; KJ_j of prev (its partial gradients have arrived) and KJP'_j of cur ===========
+        // ===== F2: member scalars out; KJP'_j of cur (wave-local: it stays in registers until the next F1) ==========
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
             bstore4(rsX, XO.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
-        // Straight-line on purpose: in the first iteration (no prev) the loads go out of bounds and read zeros, in the
-        // last one (no cur) KJP' is computed from stale images and dropped; only the counter add and the KJ store are
-        // conditional.  (With the loads and the sums under separate `if (have_prev)`s hipcc split the loop body on that
-        // flag, put the loads a region away from their uses and parked them in scratch: a full wait per load.)
         if (want_grad && has_spk) {
             GE2E_T2_LANE();
-            GE2E_T2_CONSTS();
-            {   // my speaker's partial gradients from the seven other members (they land under KJP' below)
-                const unsigned vrow = (dact && have_prev) ? (unsigned)d4 * 4u : OOB;
+            // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
+            kjp = zero4();
+            const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
+            const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
 #pragma unroll
-                for (int mm = 1; mm < TEAM; ++mm)
-                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
-            }
-            const float4 kjp_prev = kjp;
-            {   // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
-                kjp = zero4();
-                const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
-                const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
-#pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    if (i < M) {
-                        const float c3 = RS[(rbase + i) * 8 + 6];
-                        const int off = (rbase + i) * P + min(d4, D - 4);
-                        const h4 eh = *reinterpret_cast<const h4*>(ETh + off), el = *reinterpret_cast<const h4*>(ETl + off);
-                        kjp.x = fmaf((float)eh[0], c3, fmaf((float)el[0], c3, kjp.x));
-                        kjp.y = fmaf((float)eh[1], c3, fmaf((float)el[1], c3, kjp.y));
-                        kjp.z = fmaf((float)eh[2], c3, fmaf((float)el[2], c3, kjp.z));
-                        kjp.w = fmaf((float)eh[3], c3, fmaf((float)el[3], c3, kjp.w));
-                    }
+            for (int i = 0; i < MR; ++i) {
+                if (i < M) {
+                    const float c3 = RS[(rbase + i) * 8 + 6];
+                    const int off = (rbase + i) * P + min(d4, D - 4);
+                    const h4 eh = *reinterpret_cast<const h4*>(ETh + off), el = *reinterpret_cast<const h4*>(ETl + off);
+                    kjp.x = fmaf((float)eh[0], c3, fmaf((float)el[0], c3, kjp.x));
+                    kjp.y = fmaf((float)eh[1], c3, fmaf((float)el[1], c3, kjp.y));
+                    kjp.z = fmaf((float)eh[2], c3, fmaf((float)el[2], c3, kjp.z));
+                    kjp.w = fmaf((float)eh[3], c3, fmaf((float)el[3], c3, kjp.w));
                 }
-                kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
-                if (!dact) kjp = zero4();
             }
-            {
-                // fixed order (own slice first, then members member+1 .. member+7 mod 8): deterministic
-                float4 gsum = ownp;
-#pragma unroll
-                for (int m = 0; m < TEAM - 1; ++m) { gsum.x += part[m].x; gsum.y += part[m].y; gsum.z += part[m].z; gsum.w += part[m].w; }
-                // every partial of this speaker has been read (the sums above waited for them; nothing of this wave's
-                // is behind them that the counted wait would have to skip): the single gC buffer may be rewritten
-                asm volatile("" :: "v"(gsum.x), "v"(gsum.y), "v"(gsum.z), "v"(gsum.w));
-                if (lane == 0 && have_prev) add_agent(&fl->c3, 1u);
-                gsum = scale4(gsum, w * kSplitInv2);
-                float cf[1] = {dot4(gsum, cj_prev)};
-                wave_sum_to_sgpr<1>(cf);
-                const float coefc = cf[0];
-                const float f = kap_prev * coefc, sc = rn_prev * inv_m;
-                if (dact && have_prev)
-                    *reinterpret_cast<float4*>(KJ + wid * D + d4) =
-                        make_float4((gsum.x - f * cj_prev.x) * sc + kjp_prev.x, (gsum.y - f * cj_prev.y) * sc + kjp_prev.y,
-                                    (gsum.z - f * cj_prev.z) * sc + kjp_prev.z, (gsum.w - f * cj_prev.w) * sc + kjp_prev.w);
-            }
+            kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
+            if (!dact) kjp = zero4();
         }
-        if (want_grad) __syncthreads();
-        GE2E_PROF(5);
-
-        // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ================
-        // The sums are formed IN the held registers and stored from there: nothing writes those registers again before
-        // the next GE.  (A store's data registers must not be reused soon after it: with the memory pipe backed up a
-        // queued store reads its data late.)  All KJ reads first, then the sums and stores: written as one loop hipcc
-        // recycles ONE temporary and serialises ten LDS round trips per wave (2.8 k cycles for the older wave of a SIMD,
-        // 6 k for the younger).  Tried and dropped: the stores under GC's MFMAs -- the wave blocks at store issue and
-        // GC went from 6 k to 10 k cycles (-7 % overall).
-#define T2_DE_STORES()                                                                                                     \
-    do {                                                                                                                   \
-            GE2E_T2_LANE();                                                                                                \
-_Pragma("unroll")                                                                                                          \
-            for (int i = 0; i < NTI; ++i) {                                                                                \
-                float4 kjv[RBC];                                                                                           \
-_Pragma("unroll")                                                                                                          \
-                for (int rb = 0; rb < RBC; ++rb)                                                                           \
-                    if (CT_DE || rb < RBr) {                                                                               \
-                                                                                                                           \
-                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
-                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
-                        kjv[rb] = *reinterpret_cast<const float4*>(KJ + min((r * L.mul_m) >> 16, 7) * D + min(c, D - 4));  \
-                    }                                                                                                      \
-_Pragma("unroll")                                                                                                          \
-                for (int rb = 0; rb < RBC; ++rb)                                                                           \
-                    if (CT_DE || rb < RBr) {                                                                               \
-                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
-                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
-                        const bool ok = r < R_my && T2_DT(i) < NT;                                                         \
-                        held[i][rb].x += kjv[rb].x; held[i][rb].y += kjv[rb].y;                                            \
-                        held[i][rb].z += kjv[rb].z; held[i][rb].w += kjv[rb].w;                                            \
-                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + c) * 4u : OOB, held[i][rb]);      \
-                    }                                                                                                      \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
-            }                                                                                                              \
-    } while (0)
-        // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
-        // stores wait to issue.  Tried and dropped: the stores under GC's MFMAs (GC 6 k -> 10 k cycles, -7 % overall);
-        // the younger wave of every SIMD running GC first and storing after it (its GC + stores take the same 11 k).
-        if (want_grad && have_prev) T2_DE_STORES();
-#undef T2_DE_STORES
-        GE2E_PROF(6);
-        if (!have_cur) break;
+        GE2E_PROF(12);
 
         if (want_grad) {
             // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
@@ -898,68 +956,9 @@ _Pragma("unroll")                                                               
 #undef T2_GA_LOAD
             GE2E_PROF(7);
         }
-        GE2E_PROF(9);
-        if (want_grad) {
-            // ===== GE: gE^T[d][r] = sum_k CH[k][d] G[r][k]; ra gE + c1 e-hat stays in registers ======================
-            // The G fragments of the next row block and this block's epilogue operands are requested before the MFMAs.
-            {
-                GE2E_T2_LANE();
-                int rbg = RB;
-                asm volatile("" : "+s"(rbg));
-                h8 gb[2][2][2];             // [set][s2][hi, lo]: G rows 16 rb + l15, slots 32 s2 + 8 q ..
-#define T2_GE_LOAD(RB_)                                                                                      \
-    do {                                                                                                     \
-        const int r_ = 16 * (RB_) + l15;                                                                     \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
-            gb[(RB_) & 1][s2][0] = frag_row(Gh + r_ * GP + 32 * s2 + 8 * q);                                 \
-            gb[(RB_) & 1][s2][1] = frag_row(Gl + r_ * GP + 32 * s2 + 8 * q);                                 \
-        }                                                                                                    \
-    } while (0)
-                T2_GE_LOAD(0);
-#pragma unroll
-                for (int rb = 0; rb < RBC; ++rb) {
-                    if (rb < rbg) {
-                        const int r = 16 * rb + l15;
-                        if (rb > 0) T2_GE_LOAD(rb);
-                        const float2 rc = *reinterpret_cast<const float2*>(RS + r * 8 + 4);   // ra, c1
-                        h4 eh[NTI], el[NTI];
-#pragma unroll
-                        for (int i = 0; i < NTI; ++i) {
-                            const int eo = r * P + min(16 * T2_DT(i), D - 16) + 4 * q;
-                            eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
-                            el[i] = *reinterpret_cast<const h4*>(ETl + eo);
-                        }
-                        // lane (r = l15, q) ends with gE[r][16 dt + 4 q + i].  
-#pragma unroll
-                        for (int i = 0; i < NTI; ++i) {
-                            f32x4 acc = acc_zero4();
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2)
-                                mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
-                            held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
-                                                      fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
-                                                      fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
-                                                      fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
-                        }
-                        if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
-                        __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
-                    }
-                }
-#undef T2_GE_LOAD
-            }
-        }
-        GE2E_PROF(10);
-        // The next batch's rows are requested only now, after GE: requested before it (round 2) their 40 registers sat under
-        // GE's fragments and accumulators, the kernel's register peak (237 against 205 now), and the end barrier and the
-        // next A1's first instructions cover about as much of the HBM round trip as GE did (+4 % measured).  An L2
-        // prefetch a phase ahead (one dword per 64 bytes through the LDS-DMA path) cost 6 %: 64 lines per instruction.
-        GE2E_T2_LOAD_ROWS(bi + id.nct);
-        // the next iteration's A rewrites the ET images and the stage inside the X block
-        __syncthreads();
-        GE2E_PROF(8);
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    GE2E_PROF_FLUSH(12)
+    GE2E_PROF_FLUSH(13)
 #undef GE2E_T2_LOAD_ROWS
 #undef GE2E_T2_LANE
 #undef GE2E_T2_CONSTS

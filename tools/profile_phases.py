@@ -28,10 +28,11 @@ PHASES = {
              "P2 centroid images -> LDS", "P3 X = CH.ET^T (+ dE stores of prev)", "P4 softmax in registers",
              "P5 KJP, gE tiles, scalars + barrier", "P6 G images", "P7 partial gC, rows request, publish, barrier",
              "wait 2 (partial gradients of prev)", "P8(prev) reduce -> KJ, dE complete"],
-    "team": ["A1 centroid out; drain + signals", "A2 rows -> images", "W wait for both hand-offs",
-              "B requests, X, partials requested + barrier", "S softmax, G images + barrier",
-              "F requests, KJ(prev), KJP(cur) + barrier", "dE(prev) stores", "GC partial gC + publish", "end barrier",
-              "next rows requested", "GE", "(B up to the end of the X loop; the B line is the rest: scalars out + barrier)"],
+    "team": ["A1(cur) centroid out; drain + signals", "A2(cur) rows -> images; next rows requested", "W wait for both hand-offs",
+              "X tail: slot scalars -> LDS, barrier", "S softmax, G images + barrier",
+              "F1 KJ(prev) + barrier", "dE(prev) stores, scalars out",
+              "GC partial gC + publish", "-", "requests: centroid fragments, partial gradients", "GE(prev)", "X contraction",
+              "F2 member scalars, KJP(cur)"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
