@@ -384,11 +384,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             rn_cur = rn; kap_cur = kap;
             h4 hi, lo;
             split4(scale4(cj_cur, kSplitScale), hi, lo);
-            {   // row-major image row of slot kslot: D hi halfs, then D lo halfs
-                const unsigned vh = dact ? (unsigned)d4 * 2u : OOB;
-                const unsigned o = XO.chr[buf] + (unsigned)kslot * ROWB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + o + 2u * D, 0, 0);
+            {   // fragment-major form for X: one 1-KB block per (slot tile, hi / lo, 32-column K-step) holding the 64 lanes'
+                // 16-byte MFMA fragments in lane order (lane = 16 q + slot-in-tile), so that a consumer's load instruction
+                // reads 1 KB contiguously.  (As plain row-major rows every load instruction fetched 16 x 64 bytes, the
+                // shape the texture path likes least; eight of those per wave and batch.)  This lane holds columns d4 ..
+                // d4 + 3 of slot kslot: half a fragment.
+                const unsigned blk = (unsigned)(kslot >> 4) * (4u * NCH) + (unsigned)(lv_ >> 3);      // hi block of its K-step
+                const unsigned vh = dact ? blk * 1024u + (unsigned)(((lv_ >> 1) & 3) * 16 + (kslot & 15)) * 16u + (unsigned)(lv_ & 1) * 8u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + XO.chr[buf], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, 0);
             }
             if (dact) {   // one 8-byte write per image: a row of the stage per wave
                 *reinterpret_cast<h4*>(STG + wid * SP + d4) = hi;
@@ -490,11 +494,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         {   // every load unconditional (out-of-bounds offsets read zeros): a load under an `if` is a phi at the join, and
             // hipcc resolves it with s_waitcnt vmcnt(0) -- a full L2 round trip in front of A2
             GE2E_T2_LANE();
-            const unsigned oa = have_cur ? XO.chr[buf] + (unsigned)(16 * tX + l15) * ROWB + (unsigned)(32 * khX * NCH + 8 * q) * 2u : OOB;
+            // block (slot tile tX, hi / lo, K-step khX NCH + s) of the fragment-major centroid form, this lane's 16 bytes
+            const unsigned oa = have_cur ? XO.chr[buf] + ((unsigned)tX * (4u * NCH) + (unsigned)khX * NCH) * 1024u + (unsigned)lv_ * 16u : OOB;
 #pragma unroll
             for (int s = 0; s < NCH; ++s) {
-                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 64u * s, 0);
-                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 64u * s + 2u * D, 0);
+                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 1024u * s, 0);
+                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 1024u * s + 2048u * NCH, 0);
             }
             cstv = bload4<AUX_L2>(rsX, have_cur && tid < NC ? XO.cst[buf] + (unsigned)tid * 16u : OOB, 0);
             scv = bload4<AUX_L2>(rsX, have_prev && id.member == 0 && tid < TEAM ? XO.sc[pbuf] + (unsigned)tid * 16u : OOB, 0);

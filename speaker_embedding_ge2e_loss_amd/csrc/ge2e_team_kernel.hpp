@@ -16,7 +16,7 @@ struct TeamKFlags {
 // Per-team exchange area (byte offsets from the team's base): a function of D alone, so the kernel (templated on D)
 // folds every offset into an immediate instead of keeping a dozen SGPRs live.
 struct TeamKX {
-    unsigned chr[2];    // [64 slots][hi D | lo D] halfs      unit centroids * 2^8, row-major          (double-buffered)
+    unsigned chr[2];    // [4 slot tiles][hi, lo][D / 32 K-steps][64 lanes x 16 B]  unit centroids * 2^8 as MFMA fragments (double-buffered)
     unsigned cht[2];    // [8 members][hi, lo][D][8 slots]    the same, one 16-byte k-group per d       (double-buffered)
     unsigned cst[2];    // [64][4] floats                     1/|c|, kappa, |s|, |s|^2                  (double-buffered)
     unsigned sc[2];     // [8][4] floats                      loss, dw, db partials                     (double-buffered)
