@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     asm volatile("" : "+s"(wb_), "+s"(bb_), "+s"(mc_), "+s"(le_));                             \
     const float w = __int_as_float(wb_), bias = __int_as_float(bb_);                           \
     const float eps_cos2 = eps_cos * eps_cos;                                                  \
-    const float fM = (float)mc_, inv_m = 1.0f / fM, inv_m1 = 1.0f / (float)(mc_ - 1);          \
+    const float fM = (float)mc_, inv_m = rcp_nr(fM), inv_m1 = rcp_nr((float)(mc_ - 1));       \
     (void)w; (void)bias; (void)eps_cos2; (void)fM; (void)inv_m; (void)inv_m1; (void)le_
     const bool want_grad = p.dE != nullptr;
     const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
@@ -464,7 +464,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                                                       fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
                         }
                         if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
+#ifndef GE2E_X_NOSB_GE
                         __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
+#endif
                     }
                 }
 #undef T2_GE_LOAD
@@ -536,7 +538,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     const float sc = lane_get(rs_l, i);
                     if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(rowv[i], sc));
                 }
+#ifndef GE2E_X_NOSB_A2
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
+#endif
             }
         }
         // The next batch's rows are requested as soon as this batch's have become images: a whole iteration ahead of their
@@ -652,7 +656,9 @@ _Pragma("unroll")                                                               
                         const int t = rb * NCH + s;
                         if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
                         mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
+#ifndef GE2E_X_NOSB_X
                         __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+#endif
                     }
                     // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
                     if (rb > 0) { T2_X_STORE(rb - 1); }
@@ -678,6 +684,7 @@ _Pragma("unroll")                                                               
         // Lane (rr = lane >> 2, qq = lane & 3) holds the slots (sb + j) & 63, j = 0..15, sb = (own slot & ~3) + 16 qq:
         // aligned groups of four, and the own-speaker column is always one of values 0..3 of the lane qq == 0.
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        float c3v = 0.f, c4v = 0.f;     // row coefficients c3', c4' of row i in lane 4 i (S -> F2, same wave: no LDS trip)
         if (have_cur && want_grad && R_my < RT) {   // image rows without a speaker: the KJ rows of F1 have been lying there
             for (int i = tid; i < (RT - R_my) * GP / 8; i += 512) {
                 reinterpret_cast<float4*>(Gh + R_my * GP)[i] = zero4();
@@ -813,12 +820,14 @@ _Pragma("unroll")                                                               
                 // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
                 // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
                 const float lam = cs.x * inv_m * w;
+                const float c3p = (alpha * inv_m1 - lam * o) * kSplitInv;           // c3'
+                const float c4p = beta * inv_m1 * cs.z + lam * cs.y * o * xo;       // c4' (of c-hat_j)
+                c3v = rv && own_lane ? c3p : 0.f;
+                c4v = rv && own_lane ? c4p : 0.f;
                 if (rv && own_lane)
-                    *reinterpret_cast<float4*>(RS + r * 8 + 4) =
-                        make_float4(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
-                                    c1 * kSplitInv,                                 // c1: of the e-hat image value (2^8)
-                                    (alpha * inv_m1 - lam * o) * kSplitInv,         // c3'
-                                    beta * inv_m1 * cs.z + lam * cs.y * o * xo);    // c4' (of c-hat_j)
+                    *reinterpret_cast<float2*>(RS + r * 8 + 4) =
+                        make_float2(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
+                                    c1 * kSplitInv);                                // c1: of the e-hat image value (2^8)
                 const float og = o * kSplitScale;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gv[j] = ownj[j] ? og : gv[j];
@@ -850,18 +859,26 @@ _Pragma("unroll")                                                               
             GE2E_T2_LANE();
             // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
             kjp = zero4();
-            const float c4v = lv_ < M ? RS[(rbase + min(lv_, M - 1)) * 8 + 7] : 0.f;
-            const float bsum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_sum(c4v))));
+            float bs[1] = {c4v};
+            wave_sum_to_sgpr<1>(bs);
+            const float bsum = bs[0];
+            // all image reads first (two 8-byte reads a row), then the sums: written as one loop hipcc recycles one pair of
+            // registers and serialises the LDS round trips
+            h4 eh[MR], el[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int off = (rbase + min(i, M - 1)) * P + min(d4, D - 4);
+                eh[i] = *reinterpret_cast<const h4*>(ETh + off);
+                el[i] = *reinterpret_cast<const h4*>(ETl + off);
+            }
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
-                    const float c3 = RS[(rbase + i) * 8 + 6];
-                    const int off = (rbase + i) * P + min(d4, D - 4);
-                    const h4 eh = *reinterpret_cast<const h4*>(ETh + off), el = *reinterpret_cast<const h4*>(ETl + off);
-                    kjp.x = fmaf((float)eh[0], c3, fmaf((float)el[0], c3, kjp.x));
-                    kjp.y = fmaf((float)eh[1], c3, fmaf((float)el[1], c3, kjp.y));
-                    kjp.z = fmaf((float)eh[2], c3, fmaf((float)el[2], c3, kjp.z));
-                    kjp.w = fmaf((float)eh[3], c3, fmaf((float)el[3], c3, kjp.w));
+                    const float c3 = lane_get(c3v, 4 * i);
+                    kjp.x = fmaf((float)eh[i][0], c3, fmaf((float)el[i][0], c3, kjp.x));
+                    kjp.y = fmaf((float)eh[i][1], c3, fmaf((float)el[i][1], c3, kjp.y));
+                    kjp.z = fmaf((float)eh[i][2], c3, fmaf((float)el[i][2], c3, kjp.z));
+                    kjp.w = fmaf((float)eh[i][3], c3, fmaf((float)el[i][3], c3, kjp.w));
                 }
             }
             kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
@@ -912,7 +929,9 @@ _Pragma("unroll")                                                               
                             if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
 #pragma unroll
                             for (int b = 0; b < 2; ++b) mfma32x3(gc[b], gf[s & 1][0], gf[s & 1][1], ef[s & 1][b][0], ef[s & 1][b][1]);
+#ifndef GE2E_X_NOSB_GC
                             __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+#endif
                         }
                     }
 #undef T2_GC_LOAD
