@@ -126,6 +126,27 @@ def cpu_baseline(N, M, D, variant, budget_s=12.0):
                       f"{best_threads} threads = fastest of 8/16/32/64 on {ncpu} visible cores)"}
 
 
+def verify_launch(E, out, N, M, D, variant, w=10.0, b=-5.0):
+    """After the timed region: sampled batches of the benched launch (first, last, both sides of a team boundary, the
+    middle) against the fp64 closed-form oracle.  The oracle is the checker here, never the thing timed."""
+    from oracle import ge2e_oracle as orc
+    B = E.shape[0]
+    picks = sorted({i for i in (0, 31, 32, B // 2 - 1, B // 2, B - 1) if 0 <= i < B})
+    worst = {"max_loss_rel": 0.0, "max_dE_relfro": 0.0, "max_dw_rel": 0.0, "max_db_abs": 0.0}
+    for i in picks:
+        ref = orc.closed_form(E[i].cpu().numpy(), w, b, variant=variant)
+        dE = out.dE[i].cpu().numpy().astype(np.float64)
+        worst["max_loss_rel"] = max(worst["max_loss_rel"], abs(float(out.loss[i]) - ref["loss"]) / max(abs(ref["loss"]), 1e-30))
+        worst["max_dE_relfro"] = max(worst["max_dE_relfro"], float(np.linalg.norm(dE - ref["dE"]) / max(np.linalg.norm(ref["dE"]), 1e-30)))
+        worst["max_dw_rel"] = max(worst["max_dw_rel"], abs(float(out.dw[i]) - ref["dw"]) / max(abs(ref["dw"]), 1e-30))
+        worst["max_db_abs"] = max(worst["max_db_abs"], abs(float(out.db[i]) - ref["db"]))
+    # the north-star gate (SURVEY 8d): loss rtol 1e-4, dE rel-Frobenius 1e-4, dw rtol 1e-4, db atol 1e-4
+    ok = (worst["max_loss_rel"] <= 1e-4 and worst["max_dE_relfro"] <= 1e-4 and worst["max_dw_rel"] <= 1e-4
+          and worst["max_db_abs"] <= 1e-4 and all(np.isfinite(v) for v in worst.values()))
+    return {"batches": picks, **worst, "tolerance": "loss rtol 1e-4, dE rel-Frobenius 1e-4, dw rtol 1e-4, db atol 1e-4",
+            "oracle": "oracle.ge2e_oracle.closed_form (fp64)", "ok": bool(ok)}
+
+
 def measured_traffic(cfg_name, impl, B):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools/run_profiles.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  The counters cannot be read from inside this
@@ -137,7 +158,9 @@ def measured_traffic(cfg_name, impl, B):
             table = json.load(f)
         t = table.get(f"{cfg_name}_{impl}")
         if t and t["impl"] == impl and t["batches_per_launch"] == B and t.get("source_hash") == source_hash():
-            return t["fetch_bytes"] + t["write_bytes"]
+            return {"bytes": t["fetch_bytes"] + t["write_bytes"], "fetch_bytes_x2": t["fetch_bytes"],
+                    "write_bytes": t["write_bytes"], "profile": t.get("source"),
+                    "kernel_avg_us_in_profile": t.get("traced_kernel_avg_us"), "source_hash": t.get("source_hash")}
     except Exception:
         pass
     return None
@@ -167,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the B=1 latency legs and the exact-fp32 comparison (profiling runs: only the benched kernel)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle check of sampled batches")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: ranks, rendezvous (gloo), the bucket all-reduce and the JSON line only; value is null")
     args = ap.parse_args()
@@ -350,6 +374,12 @@ def main():
                 except Exception as ex:  # unsupported shape for this kernel
                     extra["exact_f32"] = {"impl": cand, "value": None, "note": str(ex)[:120]}
 
+    verify = None
+    if rank == 0 and not dry and args.mode == "loss" and not args.no_verify and N * N * M * D <= 64 * 64 * 10 * 256 * 64:
+        step()   # the benched implementation's outputs (the exact-fp32 leg may have run since)
+        torch.cuda.synchronize()
+        verify = verify_launch(E, out, N, M, D, variant)
+
     if rank == 0:
         total_batches = B * args.steps * world
         value = None if dry else total_batches / tmax
@@ -373,13 +403,16 @@ def main():
                       "mfma_frac": issued_tf / MFMA_F16_PEAK_TF if split else None}
             if args.mode == "train-step":
                 common["note"] = "launch time here includes the bucket all-reduce (train-step mode)"
+            # HBM-side bytes of this launch: not measurable in-process -- taken from the committed rocprofv3 PMC passes of
+            # the same command, only while the kernel sources still hash to what was profiled (else null)
+            tp = measured_traffic(args.config, impl, B)
             if mfma_bound:
                 roof = {"bound": "mfma", "achieved": issued_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": issued_tf / MFMA_F16_PEAK_TF, "traffic": measured_traffic(args.config, impl, B),
+                        "frac": issued_tf / MFMA_F16_PEAK_TF, "traffic": (tp or {}).get("bytes"), "traffic_from_profile": tp,
                         "achieved_is": "issued f16 MFMA flops = 3 x algorithmic (split-fp16x3)", **common}
             else:
                 roof = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, impl, B), **common}
+                        "frac": alg_gbs / HBM_PEAK_GBS, "traffic": (tp or {}).get("bytes"), "traffic_from_profile": tp, **common}
         name = {"loss": "GE2E loss+backward throughput", "train-step": "GE2E data-parallel train-step throughput "
                 "(loss+backward + flat-bucket grad all-reduce)"}[args.mode]
         line = {
@@ -401,6 +434,8 @@ def main():
         if variant == "contrast":
             line["parity"] = ("unpinned: the reference has no contrast variant (s3 implements softmax only); checked "
                               "against the fp64 closed-form oracle and finite differences only")
+        if verify is not None:
+            line["verify"] = verify
         line.update(extra)
         if train:
             line["train_step"] = train
@@ -409,6 +444,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not dry and args.mode == "loss":
             line["cpu_baseline"] = cpu_baseline(N, M, D, variant)
         print(json.dumps(line), flush=True)
+    if dist:
+        if world > 1:
+            dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+    if verify is not None and not verify["ok"]:
+        raise SystemExit("bench.py: the benched launch does not match the oracle: " + json.dumps(verify))
     if dist:
         if world > 1:
             dist.barrier()

@@ -259,6 +259,22 @@ int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, cons
     return run(p, GE2E_IMPL_TEAM, workspace, workspace_bytes, stream);
 }
 
+// GE2E_IMPL_TEAM on at most `max_workgroups` workgroups (a multiple of 64: eight per XCD form one team): many batches
+// through few teams, so that the hand-off counters of a team run far beyond what a full-size launch reaches.
+int ge2e_selftest_team_grid(const float* E, int B, int N, int M, int D, const float* w, const float* b, float eps_cos,
+                            float eps, int variant, float* loss, float* per_emb_loss, float* dE, float* dw, float* db,
+                            void* workspace, size_t workspace_bytes, void* stream, int max_workgroups) {
+    if (!E || !w || !b || !loss) return GE2E_ERR_NULL;
+    if (dE && (!dw || !db)) return GE2E_ERR_NULL;
+    if (max_workgroups < 64) return GE2E_ERR_SHAPE;
+    Problem p{};
+    p.E = E; p.w = w; p.b = b; p.loss = loss; p.per = per_emb_loss;
+    p.dE = dE; p.dw = dw; p.db = db; p.cos_out = nullptr;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = variant; p.eps_cos = eps_cos; p.eps = eps;
+    p.grid_cap = max_workgroups;
+    return run(p, GE2E_IMPL_TEAM, workspace, workspace_bytes, stream);
+}
+
 int ge2e_selftest_split_gemm(const float* A, const float* Bm, const float* G, float* X, float* GE, float* GC,
                              void* stream) {
     if (!A || !Bm || !G || !X || !GE || !GC) return GE2E_ERR_NULL;

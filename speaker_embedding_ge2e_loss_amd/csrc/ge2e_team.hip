@@ -1007,7 +1007,9 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     int nb = 0;
     err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
     if (err != hipSuccess) return err;
-    const int grid = team_grid(p.B);
+    int grid = team_grid(p.B);
+    if (p.grid_cap > 0 && p.grid_cap < grid)      // diagnostics: fewer teams, more batches through each (whole XCD rounds)
+        grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;
     if (nb < 1 || grid > nb * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
     hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
     return hipGetLastError();

@@ -176,3 +176,74 @@ def test_hand_off_protocol_stress(GF, impl):
             torch.cuda.synchronize()
             assert torch.equal(out.loss, first[0]) and torch.equal(out.dE, first[1]), it
             assert torch.equal(out.dw, first[2]) and torch.equal(out.db, first[3]), it
+
+
+def _device_batches(B, N, M, D, seed):
+    """normalize(randn) batches generated ON the device (a 2.7 GB stack is slow to make on the host)."""
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    e = torch.randn(B, N, M, D, generator=g, device="cuda:0", dtype=torch.float32)
+    return torch.nn.functional.normalize(e, dim=-1)
+
+
+def _check_sampled(e, o, picks, w=10.0, b=-5.0):
+    for i in picks:
+        ref = orc.closed_form(e[i].cpu().numpy(), w, b)
+        assert np.allclose(float(o.loss[i]), ref["loss"], rtol=2e-5), i
+        assert rel_fro(o.dE[i].cpu().numpy(), ref["dE"]) < 2e-5, i
+        assert np.allclose(float(o.dw[i]), ref["dw"], rtol=1e-4, atol=1e-4), i
+        assert np.allclose(float(o.db[i]), ref["db"], atol=1e-4), i
+
+
+@pytest.mark.parametrize("impl", ("team", "auto"))
+def test_benched_launch_size(GF, impl):
+    """The launch bench.py times: B = 4096 at the metric shape, 128 pipelined batches per team.  Every output finite,
+    sampled batches (first, last, team boundaries, the middle, a few random ones) against the fp64 oracle, and the
+    whole launch against the one-workgroup-per-batch kernel."""
+    B, N, M, D = 4096, 64, 10, 256
+    e = _device_batches(B, N, M, D, 77)
+    w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda:0")  # noqa: E731
+    out = GF.LossOutputs(loss=nan(B), per=None, dE=nan(B, N, M, D), dw=nan(B), db=nan(B))
+    o = GF.loss_fwd_bwd(e, w, b, impl=impl, out=out)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.loss).all()) and bool(torch.isfinite(o.dw).all()) and bool(torch.isfinite(o.db).all())
+    assert bool(torch.isfinite(o.dE).all())
+    rng = np.random.default_rng(5)
+    _check_sampled(e, o, [0, 31, 32, 255, 256, 2047, 2048, 4064, 4095] + [int(x) for x in rng.integers(0, B, 4)])
+    of = GF.loss_fwd_bwd(e, w, b, impl="fused_split")
+    torch.cuda.synchronize()
+    assert torch.allclose(o.loss, of.loss, rtol=2e-6)
+    assert torch.allclose(o.dw, of.dw, rtol=2e-5, atol=1e-6) and torch.allclose(o.db, of.db, atol=2e-5)
+    num = (o.dE - of.dE).flatten(1).norm(dim=1)
+    den = of.dE.flatten(1).norm(dim=1)
+    assert float((num / den).max()) < 5e-6
+
+
+@pytest.mark.parametrize("shape,per_team", [((16, 4, 64), 1100), ((64, 10, 256), 1000)])
+def test_thousand_batches_through_one_team(GF, shape, per_team):
+    """The launch capped to 64 workgroups = one team per XCD (ge2e_selftest_team_grid): every team works through a
+    thousand batches, its hand-off counters reach 8000 (c1, c2) and N x 1000 (c3) -- far beyond the 128 batches per
+    team of the benched launch.  Results against the one-workgroup-per-batch kernel (all) and the oracle (sampled)."""
+    from speaker_embedding_ge2e_loss_amd import _lib
+    lib = _lib.load()
+    N, M, D = shape
+    B = 8 * per_team
+    dev = torch.device("cuda:0")
+    e = _device_batches(B, N, M, D, 91)
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    nan = lambda *s: torch.full(s, float("nan"), device=dev)  # noqa: E731
+    o = GF.LossOutputs(loss=nan(B), per=None, dE=nan(B, N, M, D), dw=nan(B), db=nan(B))
+    ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", "team"), dev)
+    rc = lib.ge2e_selftest_team_grid(e.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), 1e-8, 1e-6, 0,
+                                     o.loss.data_ptr(), None, o.dE.data_ptr(), o.dw.data_ptr(), o.db.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream, 64)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.loss).all()) and bool(torch.isfinite(o.dE).all())
+    _check_sampled(e, o, [0, 7, 8, B // 2, B - 9, B - 1])
+    of = GF.loss_fwd_bwd(e, w, b, impl="fused_split")
+    torch.cuda.synchronize()
+    assert torch.allclose(o.loss, of.loss, rtol=2e-6)
+    num = (o.dE - of.dE).flatten(1).norm(dim=1)
+    den = of.dE.flatten(1).norm(dim=1)
+    assert float((num / den).max()) < 5e-6

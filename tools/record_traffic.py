@@ -31,6 +31,17 @@ def counter(d, name):
     return sum(per_kernel.values()), {f"{k[0][:60]} grid={k[1]}": v for k, v in per_kernel.items()}
 
 
+def traced_launch_us(d):
+    """average duration of the largest-grid ge2e kernel in the kernel-trace pass of the same command (kernel_stats.csv)"""
+    try:
+        rows = list(csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))))
+        rows = [r for r in rows if "ge2e" in r["Name"]]
+        best = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        return float(best["AverageNs"]) / 1e3, best["Name"][:80]
+    except Exception:
+        return None, None
+
+
 def main():
     d, cfg, impl, B, label = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     f, fk = counter(d, "fetch")
@@ -44,6 +55,7 @@ def main():
         "fetch_bytes": int(f * 1024 * 2), "write_bytes": int(w * 1024),
         "per_kernel_fetch_KiB": fk, "per_kernel_write_KiB": wk,
         "source_hash": source_hash(),
+        "traced_kernel_avg_us": traced_launch_us(d)[0], "traced_kernel": traced_launch_us(d)[1],
         "source": f"{label} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                   f"MI355X_MICROARCH.md HBM section)",
     }
