@@ -240,14 +240,46 @@ __device__ __forceinline__ void unit_stats(float sq, float eps_cos, float& rn, f
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Compute units of the CURRENT device, asked on every call (no per-process cache: a process may drive several devices,
-// and a partitioned MI355X shows fewer).  Without a visible device (build host) size queries answer for a whole MI355X.
+// Compute units of the CURRENT device.  Looked up once per device and process (a process may drive several devices, and
+// a partitioned MI355X shows fewer CUs): hipGetDevice is a thread-local read, the attribute query is not, and a launch
+// asks several times.  Without a visible device (build host) size queries answer for a whole MI355X.
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) ? dev : -1;
+}
 inline int device_cu_count() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+    static int cache[kMaxDevices] = {};          // 0 = not asked yet; racing writers store the same value
+    const int dev = current_device_slot();
+    if (dev >= 0 && cache[dev] > 0) return cache[dev];
+    int d = 0, n = 0;
+    if (hipGetDevice(&d) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) {
+        if (dev >= 0) cache[dev] = n;
         return n;
+    }
     return 256;
+}
+// Per-(device, kernel) launch state of a kernel with dynamic LDS: the opt-in attribute is set and the occupancy asked
+// once per device for the largest LDS request seen, not on every call (two HIP API calls per launch otherwise).
+struct KernelLaunchState {
+    unsigned lds[kMaxDevices] = {};   // bytes the attribute has been raised to
+    int blocks[kMaxDevices] = {};     // hipOccupancyMaxActiveBlocksPerMultiprocessor at that size
+};
+inline hipError_t prepare_kernel(KernelLaunchState& st, const void* fn, int threads, unsigned lds_bytes, int* blocks_per_cu) {
+    const int dev = current_device_slot();
+    if (dev >= 0 && st.lds[dev] == lds_bytes && st.blocks[dev] > 0) {
+        if (blocks_per_cu) *blocks_per_cu = st.blocks[dev];
+        return hipSuccess;
+    }
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (err != hipSuccess) return err;
+    int nb = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds_bytes);
+    if (err != hipSuccess) return err;
+    if (dev >= 0 && nb > 0) { st.lds[dev] = lds_bytes; st.blocks[dev] = nb; }
+    if (blocks_per_cu) *blocks_per_cu = nb;
+    return hipSuccess;
 }
 
 }  // namespace ge2e

@@ -667,8 +667,8 @@ size_t fused_split_workspace_bytes(int B, int N, int M, int D) {
 
 template <int NCH>
 static hipError_t launch_nch(const Problem& p, const FusedWs& L, size_t lds, hipStream_t stream) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_fused_split_kernel<NCH>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static KernelLaunchState state;     // one per instantiation; per-device entries inside
+    hipError_t err = prepare_kernel(state, reinterpret_cast<const void*>(ge2e_fused_split_kernel<NCH>), 512, (unsigned)lds, nullptr);
     if (err != hipSuccess) return err;
     int grid = fused_split_grid(p.B);
     if (p.grid_cap > 0 && grid > p.grid_cap) grid = p.grid_cap;

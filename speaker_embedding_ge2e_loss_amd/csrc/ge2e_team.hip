@@ -992,7 +992,9 @@ _Pragma("unroll")                                                               
 template <int NCH, int MR, int RBT, bool CONTRAST>
 static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST>);
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
+    static KernelLaunchState state;     // one per instantiation; per-device entries inside
+    int nb = 0;
+    hipError_t err = prepare_kernel(state, fn, 512, (unsigned)L.lds_bytes, &nb);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
     if (err != hipSuccess) return err;
@@ -1004,9 +1006,6 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
     // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
     // behind it redoes every batch with the one-workgroup-per-batch kernel.
-    int nb = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, L.lds_bytes);
-    if (err != hipSuccess) return err;
     int grid = team_grid(p.B);
     if (p.grid_cap > 0 && p.grid_cap < grid)      // diagnostics: fewer teams, more batches through each (whole XCD rounds)
         grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;

@@ -44,6 +44,46 @@ def _stream_ptr(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` that costs nothing when dev is already current (the usual case: ~5 us of host time
+    per call otherwise, on a path whose kernel takes 30 us)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev: torch.device):
+        self.idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+# Per-(shape, device) workspace sizes and per-(device, stream) workspace tensors of the module path.  The size depends on
+# the device (its CU count), so the query runs with that device current.  A workspace is reused only by launches on the
+# SAME stream, which the stream itself serialises; callers that pass `workspace=` are unaffected.
+_ws_bytes_cache: dict = {}
+_ws_cache: dict = {}
+
+
+def _workspace_for(lib, dev: torch.device, stream: int, key: tuple) -> torch.Tensor:
+    need = _ws_bytes_cache.get(key)
+    if need is None:
+        need = _ws_bytes_cache[key] = int(lib.ge2e_workspace_bytes(*key[:6]))
+    k = (key[6], stream)
+    ws = _ws_cache.get(k)
+    if ws is None or ws.numel() < need:
+        ws = _ws_cache[k] = alloc_workspace(need, dev)
+    return ws
+
+
 def workspace_bytes(B: int, N: int, M: int, D: int, variant: str = "softmax", impl: str = "auto") -> int:
     return int(_lib.load().ge2e_workspace_bytes(B, N, M, D, _lib.VARIANTS[variant], _lib.IMPLS[impl]))
 
@@ -99,15 +139,15 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
             dw=sc[1] if need_grad else None,
             db=sc[2] if need_grad else None)
     v, im = _lib.VARIANTS[variant], _lib.IMPLS[impl]
-    need = lib.ge2e_workspace_bytes(B, N, M, D, v, im)
-    if workspace is None:
-        workspace = alloc_workspace(need, dev)
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(dev):
+    with _on_device(dev) as guard:
+        stream = _stream_ptr(e4)
+        if workspace is None:
+            workspace = _workspace_for(lib, dev, stream, (B, N, M, D, v, im, guard.idx))
         code = lib.ge2e_loss_fwd_bwd(
             e4.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), eps_cos, eps, v, im,
             out.loss.data_ptr(), ptr(out.per), ptr(out.dE), ptr(out.dw), ptr(out.db),
-            workspace.data_ptr(), workspace.numel(), _stream_ptr(e4))
+            workspace.data_ptr(), workspace.numel(), stream)
     _lib.check(code, "ge2e_loss_fwd_bwd")
     return out
 
@@ -388,13 +428,15 @@ class _GE2ELossFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         dE, dw, db = ctx.saved_tensors
-        g = grad_out.reshape(-1).to(torch.float32).contiguous()  # (1,) or (B,)
+        g = grad_out                                             # 0-dim or (B,)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
         B, N, M, D = dE.shape
         need_e, need_w, need_b = ctx.needs_input_grad[:3]
         # one launch: gE = g dE, gw = sum g dw, gb = sum g db (no host sync; out of place, so a retained graph may run again)
         gE = torch.empty_like(dE) if need_e else None
         gwb = torch.empty(2, dtype=torch.float32, device=dE.device) if (need_w or need_b) else None
-        with torch.cuda.device(dE.device):
+        with _on_device(dE.device):
             code = _lib.load().ge2e_scale_grads(
                 dE.data_ptr(), dw.data_ptr(), db.data_ptr(), g.data_ptr(), g.numel(), B, N, M, D,
                 gE.data_ptr() if need_e else None, gwb.data_ptr() if need_w else None,
@@ -402,8 +444,8 @@ class _GE2ELossFunction(torch.autograd.Function):
         _lib.check(code, "ge2e_scale_grads")
         if need_e and ctx.squeeze:
             gE = gE[0]
-        gw = gwb[0].reshape(ctx.w_shape) if need_w else None
-        gb = gwb[1].reshape(ctx.b_shape) if need_b else None
+        gw = (gwb[0] if len(ctx.w_shape) == 0 else gwb[0].reshape(ctx.w_shape)) if need_w else None
+        gb = (gwb[1] if len(ctx.b_shape) == 0 else gwb[1].reshape(ctx.b_shape)) if need_b else None
         return gE, gw, gb, None, None, None, None
 
 
@@ -411,7 +453,10 @@ def ge2e_loss(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, eps
               eps_cos: float = EPS_COS, variant: str = "softmax", impl: str = "auto") -> torch.Tensor:
     """Differentiable GE2E loss: 0-dim for (N,M,D) input, (B,) for (B,N,M,D)."""
     _require_cuda(embeddings, "embeddings")
-    if embeddings.dtype != torch.float32:
-        # the reference is dtype-generic (SURVEY 8a/a2); the kernels compute in fp32
+    in_dtype = embeddings.dtype
+    if in_dtype != torch.float32:
+        # the reference is dtype-generic (s3:19-30 accepts fp16 / fp64 and returns that dtype, SURVEY 8a/a2); the kernels
+        # compute in fp32, the casts either side are differentiable torch ops
         embeddings = embeddings.float()
-    return _GE2ELossFunction.apply(embeddings, w, b, float(eps), float(eps_cos), variant, impl)
+    loss = _GE2ELossFunction.apply(embeddings, w, b, float(eps), float(eps_cos), variant, impl)
+    return loss if in_dtype == torch.float32 else loss.to(in_dtype)

@@ -292,6 +292,13 @@ def test_module_autograd_matches_reference_semantics(GF):
     # fp64 input is accepted (dtype-generic reference), computed in fp32
     l64 = mod(torch.as_tensor(g["E"], device="cuda:0").double())
     assert np.allclose(l64.item(), mod(torch.as_tensor(g["E"], device="cuda:0")).item())
+    # ... and the loss comes back in the input's dtype, as from the reference (s3:19-30 computes in whatever it is given)
+    assert l64.dtype == torch.float64
+    e16 = torch.as_tensor(g["E"], device="cuda:0").half().requires_grad_(True)
+    l16 = mod(e16)
+    assert l16.dtype == torch.float16
+    l16.backward()
+    assert e16.grad is not None and e16.grad.dtype == torch.float16
 
 
 def test_batched_module_backward(GF):
