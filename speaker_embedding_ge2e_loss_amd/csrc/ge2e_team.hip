@@ -335,6 +335,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const bool dact = d4 < D;                                           \
     (void)l15; (void)q; (void)d4; (void)dact
 
+#ifdef GE2E_X_PRIO
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // the younger wave of each SIMD
+#endif
     GE2E_PROF_DECL(13)
     GE2E_T2_LOAD_ROWS(id.team);
     const TeamId id_outer = id;
@@ -615,22 +618,17 @@ _Pragma("unroll")                                                               
         // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
         // stores wait to issue.  Tried and dropped: the stores under GC's MFMAs (GC 6 k -> 10 k cycles, -7 % overall);
         // the younger wave of every SIMD running GC first and storing after it (its GC + stores take the same 11 k).
+        // dE(prev) and X(cur) are independent (the stores read KJ and the held registers, X reads the images and writes the
+        // X block): the two waves of a SIMD take them in OPPOSITE order -- waves 0-3 store while waves 4-7 contract, then
+        // the other way round -- so a wave blocked at store issue shares its SIMD with one that feeds the matrix pipe.
+#ifndef GE2E_X_NO_PP_DEX
+#pragma unroll 1
+        for (int st_ = 0; st_ < 2; ++st_) {
+        if ((st_ == 0) == (wid < 4)) {
+#endif
         if (want_grad && have_prev) T2_DE_STORES();
-#undef T2_DE_STORES
-        GE2E_PROF(6);
-        // ---- previous batch: scalars out ----------------------------------------------------------------------------
-        if (have_prev) {
-            if (id.member == 0 && wid == 0) {
-                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
-                if (lane == 0) {
-                    if (p.loss) p.loss[bi - id.nct] = l;
-                    if (p.dw) p.dw[bi - id.nct] = a;
-                    if (p.db) p.db[bi - id.nct] = c;
-                }
-            }
-        }
-        if (!have_cur) break;
-
+#ifndef GE2E_X_NO_PP_DEX
+        } else {
         // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
         if (have_cur) {
             GE2E_T2_LANE();
@@ -674,6 +672,68 @@ _Pragma("unroll")                                                               
 #undef T2_X_STORE
             if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
         }
+        } }
+#endif
+#undef T2_DE_STORES
+        GE2E_PROF(6);
+        // ---- previous batch: scalars out ----------------------------------------------------------------------------
+        if (have_prev) {
+            if (id.member == 0 && wid == 0) {
+                const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+                if (lane == 0) {
+                    if (p.loss) p.loss[bi - id.nct] = l;
+                    if (p.dw) p.dw[bi - id.nct] = a;
+                    if (p.db) p.db[bi - id.nct] = c;
+                }
+            }
+        }
+        if (!have_cur) break;
+
+#ifdef GE2E_X_NO_PP_DEX
+        // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
+        if (have_cur) {
+            GE2E_T2_LANE();
+            float* const XBk = khX ? XB1 : XB0;
+            const int off0 = l15 * P + 32 * khX * NCH + 8 * q;
+            h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
+            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
+#define T2_X_LOAD(T_)                                                                                     \
+    do {                                                                                                  \
+        fb[(T_) & 1][0] = frag_row(ETh + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+        fb[(T_) & 1][1] = frag_row(ETl + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+    } while (0)
+#define T2_X_STORE(RB_)                                                                       \
+    *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
+        make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
+            T2_X_LOAD(0);
+#pragma unroll
+            for (int rb = 0; rb < RBC; ++rb) {
+                if (CT_X || rb < RBr) {
+                    acc[rb & 1] = acc_zero4();
+#pragma unroll
+                    for (int s = 0; s < NCH; ++s) {
+                        const int t = rb * NCH + s;
+                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
+                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
+#ifndef GE2E_X_NOSB_X
+                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+#endif
+                    }
+                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
+                    if (rb > 0) { T2_X_STORE(rb - 1); }
+                }
+            }
+            if (CT_X) { T2_X_STORE(RBT - 1); }
+            else {
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb)
+                    if (rb == RBr - 1) { T2_X_STORE(rb); }
+            }
+#undef T2_X_LOAD
+#undef T2_X_STORE
+            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
+        }
+#endif
         GE2E_PROF(11);
         __syncthreads();
         GE2E_PROF(3);
@@ -848,6 +908,13 @@ _Pragma("unroll")                                                               
         __syncthreads();
         GE2E_PROF(4);
 
+        // F2 (vector work on the images) and GC (matrix pipe, stores) are independent: opposite order on the two waves of
+        // a SIMD, as for dE / X above
+#ifdef GE2E_X_PP_FGC
+#pragma unroll 1
+        for (int st2_ = 0; st2_ < 2; ++st2_) {
+        if ((st2_ == 0) == (wid < 4)) {
+#endif
         // ===== F2: member scalars out; KJP'_j of cur (wave-local: it stays in registers until the next F1) ==========
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
@@ -885,7 +952,9 @@ _Pragma("unroll")                                                               
             if (!dact) kjp = zero4();
         }
         GE2E_PROF(12);
-
+#ifdef GE2E_X_PP_FGC
+        } else {
+#endif
         if (want_grad) {
             // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
             // dead (requested before it they cost 32 more registers under the accumulators and the allocator spilled
@@ -980,6 +1049,9 @@ _Pragma("unroll")                                                               
 #undef T2_GA_LOAD
             GE2E_PROF(7);
         }
+#ifdef GE2E_X_PP_FGC
+        } }
+#endif
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     GE2E_PROF_FLUSH(13)
