@@ -49,12 +49,18 @@ extern "C" {
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
 #define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, the member's rows resident in LDS: E is
                                    read once.  Falls back to FUSED_SPLIT inside the same call (a gated second
-                                   launch) if the teams cannot form or a hand-off times out.  AUTO leaves it out when
-                                   GE2E_AUTO_NO_TEAM=1 is in the environment (a process sharing the GPU)      */
+                                   launch) if the teams cannot form or a hand-off times out (see
+                                   GE2E_IMPL_AUTO_NO_TEAM)                                                     */
 
 #define GE2E_IMPL_WAVE 6        /* one WAVE per batch, the batch in registers, exact fp32, no workspace: the reference's
                                    own shapes (up to 64 rows: N <= 3..12 depending on M in {2,3,4,5,6,8,10,16},
                                    D <= 256, D % 4 == 0)                                                        */
+#define GE2E_IMPL_AUTO_NO_TEAM 7 /* AUTO without GE2E_IMPL_TEAM: for callers that KNOW other streams or processes keep
+                                   CUs busy while the loss runs (overlapped collectives, a shared GPU).  The team kernel
+                                   wants its workgroups co-resident; it survives a busy device (waits bounded to a few
+                                   milliseconds, then the fall-back launch), but not choosing it saves those waits.  The
+                                   environment variable GE2E_AUTO_NO_TEAM=1 (read once per process) turns every AUTO
+                                   into this. */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */

@@ -14,9 +14,11 @@ ABI_VERSION = 1
 
 VARIANT_SOFTMAX, VARIANT_CONTRAST = 0, 1
 VARIANTS = {"softmax": VARIANT_SOFTMAX, "contrast": VARIANT_CONTRAST}
-IMPL_AUTO, IMPL_GENERIC, IMPL_FUSED_F32, IMPL_FUSED_SPLIT, IMPL_TILED, IMPL_TEAM, IMPL_WAVE = 0, 1, 2, 3, 4, 5, 6
+IMPL_AUTO, IMPL_GENERIC, IMPL_FUSED_F32, IMPL_FUSED_SPLIT, IMPL_TILED, IMPL_TEAM, IMPL_WAVE, IMPL_AUTO_NO_TEAM = 0, 1, 2, 3, 4, 5, 6, 7
 IMPLS = {"auto": IMPL_AUTO, "generic": IMPL_GENERIC, "fused_f32": IMPL_FUSED_F32,
-         "fused_split": IMPL_FUSED_SPLIT, "tiled": IMPL_TILED, "team": IMPL_TEAM, "wave": IMPL_WAVE}
+         "fused_split": IMPL_FUSED_SPLIT, "tiled": IMPL_TILED, "team": IMPL_TEAM, "wave": IMPL_WAVE,
+         # AUTO without the eight-CU team kernel: for a GPU that other streams / processes keep busy (ge2e_hip.h)
+         "auto_no_team": IMPL_AUTO_NO_TEAM}
 IMPL_NAMES = {v: k for k, v in IMPLS.items()}
 
 _fp = C.c_void_p  # device pointers travel as integers

@@ -210,8 +210,14 @@ int team_grid(int B) {
     const long want = (long)((B + MAX_XCD - 1) / MAX_XCD) * (MAX_XCD * TEAM);
     return (int)(want < cus ? want : cus);
 }
+// The fall-back runs at the one-workgroup-per-batch kernel's own grid (round 2 capped it at 32 workgroups to keep the
+// workspace small: an eighth of the chip when a large launch had to fall back).
+int team_fallback_grid(int B) {
+    const int cus = team_cu_count();
+    return B < cus ? B : cus;
+}
 static size_t team_fb_bytes(int B, int N, int M, int D) {
-    const int g = B < TEAM_FALLBACK_GRID ? B : TEAM_FALLBACK_GRID;
+    const int g = team_fallback_grid(B);
     return (size_t)g * fused_split_layout(N, M, D).stride * sizeof(float);
 }
 size_t team_workspace_bytes(int B, int N, int M, int D) {
@@ -1116,7 +1122,7 @@ hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem f = p_in;
     const TeamCtl* ctl = reinterpret_cast<const TeamCtl*>(p_in.ws);
     f.gate = &ctl->abort_;
-    f.grid_cap = TEAM_FALLBACK_GRID;
+    f.grid_cap = team_fallback_grid(p.B);
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
                                     align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange(p.D).stride, 256));
     return launch_fused_split(f, stream);

@@ -22,7 +22,12 @@ namespace ge2e {
 
 constexpr int TEAM = 8;            // workgroups (CUs) per batch
 constexpr int MAX_XCD = 8;
-constexpr unsigned TEAM_SPIN_LIMIT = 1u << 22;
+// Every wait is bounded by TIME (s_memrealtime: the constant 100 MHz counter), not by a poll count: a hand-off between
+// resident workgroups takes microseconds, so a member that has waited milliseconds is not going to be served -- another
+// stream or process holds CUs the launch counted on -- and the sooner the abort word rises, the sooner the gated
+// fall-back launch behind the kernel does the work.  (Round 2 counted 2^22 polls of s_sleep 2: seconds.)
+constexpr unsigned long long TEAM_FORM_TICKS = 200000ull;      // 2 ms: every workgroup of the grid has started
+constexpr unsigned long long TEAM_HANDOFF_TICKS = 400000ull;   // 4 ms: a hand-off inside a running team
 
 // Control block at the head of the workspace; zeroed by a memset node in front of every launch.
 // Each word that is polled or bumped sits on its own 128-byte line.
@@ -55,10 +60,16 @@ __device__ __forceinline__ unsigned add_agent(unsigned* p, unsigned v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one lane: wait until *p >= target.  Returns false when the launch is being aborted.
-__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, TeamCtl* ctl) {
-    for (unsigned it = 0; it < TEAM_SPIN_LIMIT; ++it) {
+__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, TeamCtl* ctl,
+                                           unsigned long long ticks = TEAM_HANDOFF_TICKS) {
+    if ((int)(ld_poll(p) - target) >= 0) return true;           // the common case: already there
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned it = 0;; ++it) {
         if ((int)(ld_poll(p) - target) >= 0) return true;
-        if ((it & 63) == 63 && ld_poll(&ctl->abort_)) return false;
+        if ((it & 63) == 63) {
+            if (ld_poll(&ctl->abort_)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) break;
+        }
         __builtin_amdgcn_s_sleep(2);
     }
     __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -75,7 +86,7 @@ __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket add has been performed before "arrived" moves
         add_agent(&ctl->arrived, 1u);
         int team = -1, member = 0, nct = 0;
-        if (spin_until(&ctl->arrived, gridDim.x, ctl)) {
+        if (spin_until(&ctl->arrived, gridDim.x, ctl, TEAM_FORM_TICKS)) {
             for (int i = 0; i < MAX_XCD; ++i) {
                 const int full = (int)(ld_poll(&ctl->xcd_count[i][0]) / TEAM);
                 if (i == (int)x && (int)ticket < full * TEAM) { team = nct + (int)ticket / TEAM; member = (int)ticket % TEAM; }

@@ -45,7 +45,7 @@ struct TeamKWs {
     size_t lds_bytes;
 };
 
-constexpr int TEAM_FALLBACK_GRID = 32;   // workgroups of the gated fall-back launch
+int team_fallback_grid(int B);           // workgroups of the gated fall-back launch: one per batch up to one per CU
 
 bool team_supports(int N, int M, int D);
 TeamKWs team_layout(int N, int M, int D);

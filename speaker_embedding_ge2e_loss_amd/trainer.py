@@ -29,13 +29,25 @@ class DPTrainer:
     def __init__(self, model: torch.nn.Module, loss_module: torch.nn.Module, lr: float = 0.05,
                  clip_model: float = 3.0, clip_loss: float = 1.0,
                  process_group: Optional["dist.ProcessGroup"] = None, seed: Optional[int] = None,
-                 fused_tail: bool = False):
+                 fused_tail: bool = False, shared_device: bool = False):
         # fused_tail: the encoder returns its raw projection (SpeakerEncoder(normalize=False)) and the
         # L2-normalise + un-permute + (N,M,D) layout run as one HIP kernel instead of
         # norm / divide / index_select / contiguous
         self.fused_tail = fused_tail
         self.model = model
         self.ge2e_loss = loss_module
+        # shared_device: other streams or processes keep CUs of this GPU busy while the loss runs (communication overlapped
+        # with the next step, several trainers on one device).  The loss's AUTO then leaves out the eight-CU team kernel,
+        # whose workgroups wait for each other (impl "auto_no_team", include/ge2e_hip.h).  Not needed for this trainer's
+        # own collective: the all-reduce below is ordered between backward() and the next step's loss on the stream, so the
+        # two never run side by side (tests/test_trainer_nccl_single_rank.py: 200 steps on a real RCCL group, no hand-off
+        # time-out, no latency outlier).
+        if shared_device and getattr(loss_module, "impl", None) == "auto":
+            loss_module.impl = "auto_no_team"
+        want_norm = not fused_tail
+        if getattr(model, "normalize", want_norm) != want_norm:
+            raise ValueError(f"fused_tail={fused_tail} needs an encoder with normalize={want_norm}: the L2-normalisation "
+                             "of s2:34 must happen exactly once (in the encoder, or in the fused tail kernel)")
         self.lr = lr
         self.clip_model, self.clip_loss = clip_model, clip_loss
         self.pg = process_group

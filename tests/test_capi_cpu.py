@@ -75,15 +75,29 @@ def test_workspace_and_impl_queries(lib):
         assert lib.ge2e_workspace_bytes(*shape, 0, impl) == lib.ge2e_workspace_bytes(*shape, 0, 0)
 
 
-def test_auto_leaves_the_team_kernel_out_on_request(lib, monkeypatch):
-    """GE2E_AUTO_NO_TEAM=1 (a process that shares the GPU): AUTO resolves to the one-workgroup-per-batch kernel; an
-    explicit impl=team is still honoured.  Read per call, no library state."""
-    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["team"]
-    monkeypatch.setenv("GE2E_AUTO_NO_TEAM", "1")
-    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["fused_split"]
+def test_auto_leaves_the_team_kernel_out_on_request(lib):
+    """impl = auto_no_team (a caller that shares the GPU with other streams or processes): AUTO's choice without the
+    eight-CU team kernel; an explicit impl=team is still honoured; the workspace query follows the resolved kernel."""
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, _lib.IMPLS["auto"]) == _lib.IMPLS["team"]
+    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, _lib.IMPLS["auto_no_team"]) == _lib.IMPLS["fused_split"]
     assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, _lib.IMPLS["team"]) == _lib.IMPLS["team"]
-    monkeypatch.setenv("GE2E_AUTO_NO_TEAM", "0")
-    assert lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0) == _lib.IMPLS["team"]
+    assert lib.ge2e_resolve_impl(4096, 4, 5, 256, 0, _lib.IMPLS["auto_no_team"]) == _lib.IMPLS["wave"]
+    assert lib.ge2e_workspace_bytes(8, 64, 10, 256, 0, _lib.IMPLS["auto_no_team"]) == \
+        lib.ge2e_workspace_bytes(8, 64, 10, 256, 0, _lib.IMPLS["fused_split"])
+
+
+def test_environment_opt_out_is_read_once():
+    """GE2E_AUTO_NO_TEAM=1 in the environment turns every AUTO into auto_no_team; it is read ONCE per process (not per
+    call), so it is checked in a child process."""
+    import subprocess
+    import sys
+    code = ("from speaker_embedding_ge2e_loss_amd import _lib; lib = _lib.load(); "
+            "print(lib.ge2e_resolve_impl(1, 64, 10, 256, 0, 0))")
+    import os
+    env = dict(os.environ, GE2E_AUTO_NO_TEAM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert int(out.stdout.strip().splitlines()[-1]) == _lib.IMPLS["fused_split"]
 
 
 def test_product_refuses_cpu_tensors():
