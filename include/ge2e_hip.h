@@ -96,6 +96,22 @@ int ge2e_loss_fwd_bwd(const float* E, int B, int N, int M, int D,
                       float* dE, float* dw, float* db,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The same, fed with the encoder's RAW output (s2_model_GE2E_loss_speach_embed.py:34 +
+ * s4_train_embed_model.py:186-192 folded into the loss kernel's load and store stages):
+ *   Y   [B][N*M][D]  the encoder's projection BEFORE its L2-normalisation, rows in the encoder's own (permuted) order
+ *   src [B][N*M] int32 or NULL: row r of the (N,M,D) block is Y[src[r]] / |Y[src[r]]|  (the reference's `unperm`; NULL =
+ *       identity).  Each batch's src must be a permutation of 0..N*M-1.
+ *   dY  [B][N*M][D]  dLoss/dY, through the normalisation's backward (g - e (e . g)) / |y|, in Y's row order; or NULL.
+ * One launch instead of normalise + gather, loss, and the normalisation's backward + scatter; no (N,M,D) intermediate.
+ * Shapes: ge2e_raw_supported(N, M, D) != 0 (the one-wave-per-batch kernel's register-only shapes: the reference's training
+ * shapes N=2 M=16, N=4 M=5, ...); otherwise GE2E_ERR_IMPL and the caller uses ge2e_normalize_unperm + ge2e_loss_fwd_bwd.
+ */
+int ge2e_raw_supported(int N, int M, int D);
+int ge2e_loss_fwd_bwd_raw(const float* Y, const int* src, int B, int N, int M, int D,
+                          const float* w, const float* b, float eps_cos, float eps, int variant,
+                          float* loss, float* per_emb_loss, float* dY, float* dw, float* db, void* stream);
+
 /* GE2ELoss.get_cos_sim (s3:42-80): cos [B][N][M][N], leave-one-out centroid on
  * the own-speaker column, eps added to every entry.  Forward-only consumer:
  * s5_eval_model.py:42-44. */

@@ -32,6 +32,9 @@ PROTOTYPES = {
     "ge2e_loss_fwd_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float,
                                     C.c_float, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp,
                                     C.c_size_t, _fp]),
+    "ge2e_raw_supported": (C.c_int, [C.c_int] * 3),
+    "ge2e_loss_fwd_bwd_raw": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
+                                        C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ge2e_cos_sim": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp,
                                _fp, C.c_size_t, _fp]),
     "ge2e_cos_sim_centroids": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp]),

@@ -150,6 +150,26 @@ int ge2e_loss_fwd_bwd(const float* E, int B, int N, int M, int D, const float* w
     return run(p, impl, workspace, workspace_bytes, stream);
 }
 
+int ge2e_raw_supported(int N, int M, int D) { return (N >= 1 && M >= 2 && D >= 1 && wave_supports_raw(N, M, D)) ? 1 : 0; }
+
+int ge2e_loss_fwd_bwd_raw(const float* Y, const int* src, int B, int N, int M, int D, const float* w, const float* b,
+                          float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dY, float* dw,
+                          float* db, void* stream) {
+    if (!Y || !w || !b || !loss) return GE2E_ERR_NULL;
+    if (dY && (!dw || !db)) return GE2E_ERR_NULL;
+    if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
+    if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    if (!wave_supports_raw(N, M, D)) return GE2E_ERR_IMPL;
+    if (((uintptr_t)Y & 15) || ((uintptr_t)dY & 15)) return GE2E_ERR_ALIGN;
+    Problem p{};
+    p.E = Y; p.w = w; p.b = b; p.loss = loss; p.per = per_emb_loss;
+    p.dE = dY; p.dw = dw; p.db = db; p.cos_out = nullptr;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = variant; p.eps_cos = eps_cos; p.eps = eps;
+    p.log_eps = eps > 0.f ? logf(eps) : -INFINITY;
+    p.raw = 1; p.src = src;
+    return (int)launch_wave(p, (hipStream_t)stream);
+}
+
 // Forward-only similarity matrix; w and b are not applied (s5:44 applies its own).
 int ge2e_cos_sim(const float* E, int B, int N, int M, int D, float eps_cos, float eps, float* cos,
                  void* workspace, size_t workspace_bytes, void* stream) {

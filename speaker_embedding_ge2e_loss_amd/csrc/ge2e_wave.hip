@@ -49,7 +49,11 @@ __device__ __forceinline__ float rcp_q(float x) {
 // LANE r of N + 2 registers.  (2) ONCE for all rows, lane r = row r: norms, cosines, softmax / contrast, dL/dS, the
 // coefficients of the row's gradient (the part that every lane used to compute redundantly per row: ~60 of a row's
 // ~350 instructions).  (3) per row: its coefficients read back as scalars (v_readlane), the vector part of the gradient.
-template <int M, int NX>
+// RAW (ge2e_loss_fwd_bwd_raw): the rows come from the encoder's raw projection Y through the gather index
+// src and are L2-normalised in the load stage (s2:34, s4:186-189); the store stage pushes dL/dE through that normalisation,
+// dY_r = (g - e (e . g)) / |y|, and scatters it back.  Two more wave reductions a row (|y|^2 on the way in, e . g on the way
+// out) and a second read of the row, which is an L2 hit (the batch was read microseconds earlier).
+template <int M, int NX, bool RAW = false>
 __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2e_wave_kernel(Problem p) {   // large: one wave per
     static_assert(NX * M <= 64, "a row per lane in pass 2");                                                  // SIMD, AGPRs instead of scratch
     const int N_outer = p.N, D_outer = p.D;
@@ -72,11 +76,41 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
         const bool rowv = lane < NM;
         const float* Eb = p.E + (size_t)bi * NM * D + 4 * lane;
         float4 e[NX * M];
+        int srow = 0;         // RAW: lane r = the row of Y that is row r of the (N,M,D) block
+        float rny = 0.f;      // RAW: lane r = 1 / |y_r|
+        if (!RAW) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j)
+            for (int j = 0; j < NX; ++j)
 #pragma unroll
-            for (int i = 0; i < M; ++i)
-                e[j * M + i] = (act && j < N) ? *reinterpret_cast<const float4*>(Eb + (size_t)(j * M + i) * D) : z4;
+                for (int i = 0; i < M; ++i)
+                    e[j * M + i] = (act && j < N) ? *reinterpret_cast<const float4*>(Eb + (size_t)(j * M + i) * D) : z4;
+        } else {
+            srow = rowv ? (p.src ? p.src[(size_t)bi * NM + lane] : lane) : 0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const int sr = __builtin_amdgcn_readlane(srow, j * M + i);
+                    e[j * M + i] = (act && j < N) ? *reinterpret_cast<const float4*>(Eb + (size_t)sr * D) : z4;
+                }
+            // e = y / |y| (s2:34: a plain division, no epsilon), the speaker's M norms reduced together
+            static_for<0, NX>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < N) {
+                    float nn[M];
+#pragma unroll
+                    for (int i = 0; i < M; ++i) nn[i] = dot4w(e[j * M + i], e[j * M + i]);
+                    wave_sum_to_sgpr<M>(nn);
+                    static_for<0, M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        float r = __builtin_amdgcn_rsqf(nn[i]);
+                        r = r * (1.5f - 0.5f * nn[i] * r * r);
+                        e[j * M + i] = mul4(e[j * M + i], r);
+                        rny = lane_put<j * M + i>(rny, r);
+                    });
+                }
+            });
+        }
 
         // speaker sums, unit centroids (s3:34-38 + the cosine's normalisation)
         float4 s[NX], ch[NX];
@@ -240,12 +274,39 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
                     const float a = rnc[j] * inv_m;
                     const float4 kj = make_float4(fmaf(gC[j].x - t * ch[j].x, a, DU[j].x * inv_m1), fmaf(gC[j].y - t * ch[j].y, a, DU[j].y * inv_m1),
                                                   fmaf(gC[j].z - t * ch[j].z, a, DU[j].z * inv_m1), fmaf(gC[j].w - t * ch[j].w, a, DU[j].w * inv_m1));
+                    if (!RAW) {
 #pragma unroll
-                    for (int i = 0; i < M; ++i) {
-                        const int r = j * M + i;
-                        if (act)
-                            *reinterpret_cast<float4*>(Gb + (size_t)r * D) =
-                                make_float4(e[r].x + kj.x, e[r].y + kj.y, e[r].z + kj.z, e[r].w + kj.w);
+                        for (int i = 0; i < M; ++i) {
+                            const int r = j * M + i;
+                            if (act)
+                                *reinterpret_cast<float4*>(Gb + (size_t)r * D) =
+                                    make_float4(e[r].x + kj.x, e[r].y + kj.y, e[r].z + kj.z, e[r].w + kj.w);
+                        }
+                    } else {
+                        // dY_r = (g - e (e . g)) / |y| with g = dE_r, scattered to the row it came from; e is rebuilt from a
+                        // second read of y (the registers that held it carry the gradient now)
+                        float4 yh[M];
+                        float eg[M];
+#pragma unroll
+                        for (int i = 0; i < M; ++i) {
+                            const int r = j * M + i;
+                            const int sr = __builtin_amdgcn_readlane(srow, r);
+                            const float4 y = act ? *reinterpret_cast<const float4*>(Eb + (size_t)sr * D) : z4;
+                            yh[i] = mul4(y, lane_get(rny, r));
+                            e[r] = make_float4(e[r].x + kj.x, e[r].y + kj.y, e[r].z + kj.z, e[r].w + kj.w);
+                            eg[i] = dot4w(yh[i], e[r]);
+                        }
+                        wave_sum_to_sgpr<M>(eg);
+#pragma unroll
+                        for (int i = 0; i < M; ++i) {
+                            const int r = j * M + i;
+                            const int sr = __builtin_amdgcn_readlane(srow, r);
+                            const float rn = lane_get(rny, r), t = eg[i];
+                            if (act)
+                                *reinterpret_cast<float4*>(Gb + (size_t)sr * D) =
+                                    make_float4((e[r].x - t * yh[i].x) * rn, (e[r].y - t * yh[i].y) * rn,
+                                                (e[r].z - t * yh[i].z) * rn, (e[r].w - t * yh[i].w) * rn);
+                        }
                     }
                 }
             }
@@ -263,17 +324,18 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
 struct WaveShape { int M, NX, NXL; };
 constexpr WaveShape kShapes[] = {{2, 6, 12}, {3, 5, 10}, {4, 4, 10}, {5, 4, 8}, {6, 3, 8}, {8, 3, 8}, {10, 2, 6}, {16, 2, 3}};
 
-template <int M, int NX>
+template <int M, int NX, bool RAW>
 hipError_t launch_mn(const Problem& p, hipStream_t stream) {
     const int blocks_needed = (p.B + 3) / 4;
     int grid = device_cu_count() * 2;   // two workgroups (8 waves) per CU at <= 256 VGPRs
     if (grid > blocks_needed) grid = blocks_needed;
-    hipLaunchKernelGGL((ge2e_wave_kernel<M, NX>), dim3(grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((ge2e_wave_kernel<M, NX, RAW>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 template <int M, int NX, int NXL>
 hipError_t launch_m(const Problem& p, hipStream_t stream) {
-    return p.N <= NX ? launch_mn<M, NX>(p, stream) : launch_mn<M, NXL>(p, stream);
+    if (p.raw) return p.N <= NX ? launch_mn<M, NX, true>(p, stream) : hipErrorInvalidValue;   // raw rows: the small shapes only
+    return p.N <= NX ? launch_mn<M, NX, false>(p, stream) : launch_mn<M, NXL, false>(p, stream);
 }
 
 }  // namespace
@@ -287,6 +349,9 @@ bool wave_supports(int N, int M, int D) {
 
 // the large instantiations run one wave per SIMD and a single batch takes 30-45 us on its one wave: they pay from a few
 // hundred batches per launch on (the workgroup-per-batch kernel needs 27 us per 256 batches)
+// ge2e_loss_fwd_bwd_raw: the register-only instantiations (a few dozen rows: the reference's training shapes)
+bool wave_supports_raw(int N, int M, int D) { return wave_supports(N, M, D) && !wave_is_large(N, M); }
+
 bool wave_is_large(int N, int M) {
     for (const WaveShape& s : kShapes)
         if (s.M == M) return N > s.NX;

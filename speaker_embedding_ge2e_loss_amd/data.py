@@ -107,9 +107,28 @@ class GE2EBatchSampler:
         # enqueued on the stream any re-use of the block would be ordered behind
         return out
 
-    def loader(self, batch_size: int, shuffle: bool = True, generator: Optional[torch.Generator] = None) -> Iterator[torch.Tensor]:
-        """Batches of ``batch_size`` speakers, ``drop_last=True`` like s1:93-104 (RandomSampler = one torch.randperm per epoch)."""
-        n = len(self)
-        perm: List[int] = torch.randperm(n, generator=generator).tolist() if shuffle else list(range(n))
-        for i in range(0, n - batch_size + 1, batch_size):
-            yield self.batch(perm[i:i + batch_size])
+    def loader(self, batch_size: int, shuffle: bool = True, generator: Optional[torch.Generator] = None) -> "SpeakerBatchLoader":
+        """Batches of ``batch_size`` speakers, ``drop_last=True`` like the DataLoader of s1:93-104.  The result is
+        RE-ITERABLE: every ``iter()`` (every epoch of ``DPTrainer.fit``) draws a fresh speaker order, as a DataLoader over
+        a RandomSampler does.  The order is one ``torch.randperm`` from ``generator`` (or torch's global generator) per
+        epoch -- the same distribution as the reference's RandomSampler, not the same sequence: torch's sampler first draws
+        a seed from the global generator and permutes with a generator of its own."""
+        return SpeakerBatchLoader(self, batch_size, shuffle, generator)
+
+
+class SpeakerBatchLoader:
+    """Re-iterable view of a GE2EBatchSampler: one pass = one epoch of (N,M,L,F) device batches."""
+
+    def __init__(self, sampler, batch_size: int, shuffle: bool, generator: Optional[torch.Generator]):
+        if batch_size < 1 or batch_size > len(sampler):
+            raise ValueError(f"batch_size {batch_size} outside 1..{len(sampler)} speakers")
+        self.sampler, self.batch_size, self.shuffle, self.generator = sampler, batch_size, shuffle, generator
+
+    def __len__(self) -> int:
+        return len(self.sampler) // self.batch_size
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        n = len(self.sampler)
+        perm: List[int] = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n - self.batch_size + 1, self.batch_size):
+            yield self.sampler.batch(perm[i:i + self.batch_size])

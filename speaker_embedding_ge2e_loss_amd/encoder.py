@@ -29,6 +29,7 @@ class SpeakerEncoder(nn.Module):
                 nn.init.xavier_normal_(param)
         self.projection = nn.Linear(hidden, embedding)  # s2:25
         self.normalize = normalize
+        self.embedding_size = embedding   # what the trainer needs to know before the forward: the loss kernel's D
 
     @classmethod
     def from_hp(cls, hp, normalize: bool = True):

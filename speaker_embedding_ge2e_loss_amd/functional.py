@@ -365,21 +365,99 @@ def normalize_unperm(y: torch.Tensor, unperm=None, shape=None) -> torch.Tensor:
     if y.dim() != 2:
         raise ValueError(f"y must be (rows, D), got {tuple(y.shape)}")
     rows = y.shape[0]
-    src = None
-    if unperm is not None:
-        if not torch.is_tensor(unperm):
-            if sorted(unperm) != list(range(rows)):
-                raise ValueError("unperm must be a permutation of range(rows)")
-            # pinned staging + async copy: no host sync on the step's critical path
-            src = torch.tensor(unperm, dtype=torch.int32).pin_memory().to(y.device, non_blocking=True)
-        else:
-            if unperm.numel() != rows:
-                raise ValueError("unperm must have one entry per row")
-            src = unperm.to(device=y.device, dtype=torch.int32).contiguous()
+    src = _unperm_index(unperm, rows, y.device)
     e = _NormalizeUnpermFunction.apply(y.contiguous().float(), src)
     if shape is not None:
         e = e.reshape(*shape, e.shape[1])
     return e
+
+
+def _unperm_index(unperm, rows: int, device) -> Optional[torch.Tensor]:
+    """The reference's `unperm` (s4:183-186) as an int32 device tensor; a list is validated and travels through pinned
+    memory (no host sync on the step's critical path); a tensor is checked on the device only when GE2E_CHECK_INDEX=1
+    (the kernels write every output row exactly once only for a true permutation)."""
+    if unperm is None:
+        return None
+    if not torch.is_tensor(unperm):
+        if sorted(unperm) != list(range(rows)):
+            raise ValueError("unperm must be a permutation of range(rows)")
+        return torch.tensor(unperm, dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+    if unperm.numel() != rows:
+        raise ValueError("unperm must have one entry per row")
+    src = unperm.to(device=device, dtype=torch.int32).contiguous()
+    import os
+    if os.environ.get("GE2E_CHECK_INDEX") == "1":   # debug: one host sync
+        cnt = torch.bincount(src.clamp(0, rows - 1).long(), minlength=rows)
+        if bool((src < 0).any()) or bool((src >= rows).any()) or bool((cnt != 1).any()):
+            raise ValueError("unperm (tensor) is not a permutation of range(rows)")
+    return src
+
+
+def raw_supported(N: int, M: int, D: int) -> bool:
+    """Shapes ge2e_loss_raw runs as ONE launch (the one-wave-per-batch kernel's register-only shapes)."""
+    return bool(_lib.load().ge2e_raw_supported(N, M, D))
+
+
+class _GE2ELossRawFunction(torch.autograd.Function):
+    """loss(normalize(y)[unperm].view(N,M,D)) and dL/dy in ONE launch (ge2e_loss_fwd_bwd_raw)."""
+
+    @staticmethod
+    def forward(ctx, y, src, w, b, N, M, eps, eps_cos, variant):
+        lib = _lib.load()
+        rows, D = y.shape
+        dev = y.device
+        need = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
+        f32 = dict(dtype=torch.float32, device=dev)
+        sc = torch.empty(3, **f32)                                   # loss | dw | db
+        dY = torch.empty_like(y) if need else None
+        with _on_device(dev):
+            code = lib.ge2e_loss_fwd_bwd_raw(
+                y.data_ptr(), src.data_ptr() if src is not None else None, 1, N, M, D, w.data_ptr(), b.data_ptr(),
+                eps_cos, eps, _lib.VARIANTS[variant], sc.data_ptr(), None, dY.data_ptr() if need else None,
+                sc.data_ptr() + 4 if need else None, sc.data_ptr() + 8 if need else None, _stream_ptr(y))
+        _lib.check(code, "ge2e_loss_fwd_bwd_raw")
+        ctx.w_shape, ctx.b_shape = w.shape, b.shape
+        if need:
+            ctx.save_for_backward(dY, sc)
+        return sc[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        dY, sc = ctx.saved_tensors
+        g = grad_out
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
+        rows, D = dY.shape
+        need_y, need_w, need_b = (ctx.needs_input_grad[i] for i in (0, 2, 3))
+        gY = torch.empty_like(dY) if need_y else None
+        gwb = torch.empty(2, dtype=torch.float32, device=dY.device) if (need_w or need_b) else None
+        with _on_device(dY.device):
+            code = _lib.load().ge2e_scale_grads(
+                dY.data_ptr(), sc.data_ptr() + 4, sc.data_ptr() + 8, g.data_ptr(), 1, 1, rows, 1, D,
+                gY.data_ptr() if need_y else None, gwb.data_ptr() if need_w else None,
+                gwb.data_ptr() + 4 if need_b else None, _stream_ptr(dY))
+        _lib.check(code, "ge2e_scale_grads")
+        gw = (gwb[0] if len(ctx.w_shape) == 0 else gwb[0].reshape(ctx.w_shape)) if need_w else None
+        gb = (gwb[1] if len(ctx.b_shape) == 0 else gwb[1].reshape(ctx.b_shape)) if need_b else None
+        return gY, None, gw, gb, None, None, None, None, None
+
+
+def ge2e_loss_raw(y: torch.Tensor, unperm, w: torch.Tensor, b: torch.Tensor, shape, *, eps: float = SMALL_ERR,
+                  eps_cos: float = EPS_COS, variant: str = "softmax") -> torch.Tensor:
+    """``GE2ELoss(normalize(y)[unperm].reshape(N, M, D))`` for the encoder's raw projection ``y`` (rows, D) -- s2:34,
+    s4:186-189 and s3:19-30 -- as ONE launch that also yields dL/dy.  ``shape`` = (N, M); shapes outside
+    ``raw_supported`` take the two-kernel route (normalize_unperm, then ge2e_loss)."""
+    _require_cuda(y, "y")
+    if y.dim() != 2:
+        raise ValueError(f"y must be (rows, D), got {tuple(y.shape)}")
+    N, M = int(shape[0]), int(shape[1])
+    if N * M != y.shape[0]:
+        raise ValueError(f"shape {tuple(shape)} does not match {y.shape[0]} rows")
+    if not raw_supported(N, M, y.shape[1]):
+        return ge2e_loss(normalize_unperm(y, unperm, shape=(N, M)), w, b, eps=eps, eps_cos=eps_cos, variant=variant)
+    src = _unperm_index(unperm, y.shape[0], y.device)
+    return _GE2ELossRawFunction.apply(y.contiguous().float(), src, w, b, N, M, float(eps), float(eps_cos), variant)
 
 
 def eer_counts(sim_matrix: torch.Tensor, thresholds) -> torch.Tensor:

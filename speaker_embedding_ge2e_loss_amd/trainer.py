@@ -101,10 +101,29 @@ class DPTrainer:
         emb = self.model(flat[perm])[unperm]
         return emb.reshape(n_spk, n_utt, emb.shape[1]).contiguous()
 
+    def _loss_of(self, mel: torch.Tensor) -> torch.Tensor:
+        """embed + loss (s4:174-196).  With the fused tail and a shape the raw entry takes (the reference's own training
+        shapes), normalise + un-permute + loss + their backward are ONE launch on the encoder's raw projection
+        (functional.ge2e_loss_raw); otherwise embed() and the loss module."""
+        if self.fused_tail and getattr(self.ge2e_loss, "variant", None) is not None:
+            from . import functional as GF
+            n_spk, n_utt = mel.shape[0], mel.shape[1]
+            d_out = getattr(self.model, "embedding_size", None)
+            if d_out is not None and GF.raw_supported(n_spk, n_utt, int(d_out)):
+                total = n_spk * n_utt
+                flat = mel.reshape(total, mel.shape[2], mel.shape[3])
+                perm = self._rng.sample(range(total), total)
+                unperm = [0] * total
+                for i, j in enumerate(perm):
+                    unperm[j] = i
+                y = self.model(flat[perm])
+                return GF.ge2e_loss_raw(y, unperm, self.ge2e_loss.w, self.ge2e_loss.b, (n_spk, n_utt),
+                                        eps=self.ge2e_loss.hp.general.small_err, variant=self.ge2e_loss.variant)
+        return self.ge2e_loss(self.embed(mel))  # s4:196
+
     def step(self, mel: torch.Tensor) -> torch.Tensor:
         """One training step on this rank's (N,M,T,F) batch.  Returns the local loss (device tensor)."""
-        emb = self.embed(mel)
-        loss = self.ge2e_loss(emb)  # s4:196
+        loss = self._loss_of(mel)
         self._bind_grads()
         self.flat_grad.zero_()      # s4:199 (grads stay views of the bucket)
         loss.backward()             # s4:200
@@ -125,7 +144,7 @@ class DPTrainer:
         self.model.eval()       # s4:69
         losses = []
         for mel in mel_batches:
-            losses.append(self.ge2e_loss(self.embed(mel)).detach().reshape(()))
+            losses.append(self._loss_of(mel).detach().reshape(()))
         if was_training:
             self.model.train()  # s4:107
         if not losses:
@@ -152,23 +171,39 @@ class DPTrainer:
         self.model.load_state_dict(torch.load(path, map_location=dev))
 
     def fit(self, train_batches, epochs: int, test_batches=None, lr_reduce: int = 2000, epoch_print: int = 100,
-            checkpoint_dir: Optional[str] = None, checkpoint_interval: int = 200):
+            checkpoint_dir: Optional[str] = None, checkpoint_interval: int = 200, save_best_weights: bool = False,
+            min_test_loss: float = float("inf")):
         """The epoch loop of s4:137-276 without its printing: per epoch the mean of the step losses
         (s4:215), every ``epoch_print`` epochs the batched test loss (s4:225-227), LR halving every
-        ``lr_reduce`` epochs (s4:261-264), a checkpoint every ``checkpoint_interval`` (s4:266-267)
-        and a final one (s4:270).  ``train_batches`` is any re-iterable of (N,M,T,F) tensors.
+        ``lr_reduce`` epochs (s4:261-264), a checkpoint every ``checkpoint_interval`` (s4:266-267),
+        a final one (s4:270) and, with ``save_best_weights``, the best test loss so far (s4:243-254).  ``train_batches`` is any re-iterable of (N,M,T,F) tensors.
         The step losses are reduced on the device: one host read per epoch instead of one per step
         (s4:205)."""
         import os
         self.model.train()
         train_losses, test_losses = [], []
         mean = float("nan")
+        best = None
         for e in range(epochs):
             step_losses = [self.step(mel) for mel in train_batches]
-            mean = float(torch.stack(step_losses).mean()) if step_losses else float("nan")
+            if not step_losses:
+                # a one-shot generator is exhausted after the first epoch: NaN means and a checkpoint named after them
+                # would be the silent result
+                raise ValueError(f"epoch {e + 1}: train_batches yielded no batch (pass a re-iterable, e.g. "
+                                 "GE2EBatchSampler.loader(N), not a one-shot generator)")
+            mean = float(torch.stack(step_losses).mean())
             train_losses.append(mean)
             if test_batches is not None and (e + 1) % epoch_print == 0:
-                test_losses.append(self.eval_loss(test_batches))
+                tl = self.eval_loss(test_batches)
+                if tl != tl:
+                    raise ValueError(f"epoch {e + 1}: test_batches yielded no batch (pass a re-iterable)")
+                test_losses.append(tl)
+                # s4:243-254: hp.m_ge2e.save_best_weights -- a test loss under hp.m_ge2e.min_test_loss that is the best so
+                # far (ties included) is saved under the name "m_best"
+                if save_best_weights and checkpoint_dir is not None and tl < min_test_loss:
+                    best = tl if best is None else min(best, tl)
+                    if best == tl:
+                        self.save_checkpoint(os.path.join(checkpoint_dir, f"m_best_epoch_{e + 1}_L_{tl:.4f}.pth"))
             if (e + 1) % lr_reduce == 0:
                 self.halve_lr()
             if checkpoint_dir is not None and (e + 1) % checkpoint_interval == 0:

@@ -55,3 +55,63 @@ def test_shape_argument_and_bad_permutations():
     y0 = y.clone()
     y0[3] = 0
     assert not torch.isfinite(GF.normalize_unperm(y0)[3]).any()
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 256), (4, 5, 256), (4, 5, 16), (3, 8, 64), (6, 2, 128), (2, 10, 192), (1, 4, 32)])
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+@pytest.mark.parametrize("identity", [False, True])
+def test_loss_raw_is_normalize_unperm_then_loss(shape, variant, identity):
+    """ge2e_loss_raw (ONE launch on the encoder's raw projection: s2:34 + s4:186-189 in the loss kernel's load stage, the
+    normalisation's backward + scatter in its store stage) against the same statements in torch fp64 followed by the
+    oracle's expand form: loss, dL/dy (in y's own row order), dw, db."""
+    from oracle import ge2e_oracle as orc
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+    N, M, D = shape
+    if variant == "contrast" and N == 1:
+        pytest.skip("contrast needs another speaker")
+    assert GF.raw_supported(N, M, D)
+    rows = N * M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 100 + M * 10 + D)
+    y = torch.randn(rows, D, generator=g) * (0.5 + 2.0 * torch.rand(rows, 1, generator=g))   # rows of very different norm
+    perm = random.Random(rows + D).sample(range(rows), rows)
+    unperm = [0] * rows
+    for i, j in enumerate(perm):
+        unperm[j] = i
+    idx = None if identity else unperm
+
+    yr = y.double().requires_grad_(True)
+    er = yr / torch.norm(yr, dim=1).unsqueeze(1)                       # s2:34
+    if idx is not None:
+        er = er[idx]                                                   # s4:186
+    wr = torch.tensor(7.0, dtype=torch.float64, requires_grad=True)
+    br = torch.tensor(-2.5, dtype=torch.float64, requires_grad=True)
+    lr, _, _ = orc.expand_form_loss(er.reshape(N, M, D), wr, br, variant=variant)   # s4:189, s3:19-30
+    (1.7 * lr).backward()
+
+    yd = y.to(dev).requires_grad_(True)
+    w = torch.tensor(7.0, device=dev, requires_grad=True)
+    b = torch.tensor(-2.5, device=dev, requires_grad=True)
+    loss = GF.ge2e_loss_raw(yd, idx, w, b, (N, M), variant=variant)
+    (1.7 * loss).backward()
+    assert np.allclose(loss.item(), lr.item(), rtol=5e-6, atol=2e-6)   # N = 1: the loss is ~eps, an fp32 difference of O(1) terms
+    ref = yr.grad.numpy()
+    got = yd.grad.cpu().numpy()
+    assert np.linalg.norm(got - ref) <= 2e-5 * np.linalg.norm(ref) + 1e-9
+    assert np.allclose(w.grad.item(), wr.grad.item(), rtol=1e-4, atol=1e-5)
+    assert np.allclose(b.grad.item(), br.grad.item(), atol=1e-4)
+
+
+def test_loss_raw_falls_back_outside_the_wave_shapes():
+    """A shape the one-launch form does not take (N = 16, M = 6): the same call runs normalize_unperm + the loss."""
+    from oracle import ge2e_oracle as orc
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+    N, M, D = 16, 6, 64
+    assert not GF.raw_supported(N, M, D)
+    dev = torch.device("cuda:0")
+    y = torch.randn(N * M, D, generator=torch.Generator().manual_seed(4)) * 2.0
+    e = (y / y.norm(dim=1, keepdim=True)).reshape(N, M, D).numpy()
+    ref = orc.closed_form(e, 10.0, -5.0)
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    loss = GF.ge2e_loss_raw(y.to(dev), None, w, b, (N, M))
+    assert np.allclose(loss.item(), ref["loss"], rtol=2e-5)
