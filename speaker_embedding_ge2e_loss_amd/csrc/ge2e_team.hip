@@ -43,7 +43,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NC = 64;        // centroid slots: member m owns 8 m .. 8 m + 7
-constexpr int GP = 72;        // G image pitch (halfs)
+constexpr int GP = 64;        // G image pitch (halfs): 128-byte rows, 16-byte chunks XOR-swizzled by row (g_off)
 constexpr int XP = 68;        // X block pitch (floats)
 constexpr int STGPAD = 32;    // centroid stage: rows 16 banks apart -> the transposing reads of a 4 x 32 block never collide
 constexpr int RTMAX = 80;     // rows of a member's images
@@ -154,6 +154,41 @@ __device__ __forceinline__ void pair_lines1(float& a, float& b) {
 #define T2_PAIR_LINES(A_, B_) \
     do { pair_lines1((A_).x, (B_).x); pair_lines1((A_).y, (B_).y); pair_lines1((A_).z, (B_).z); pair_lines1((A_).w, (B_).w); } while (0)
 
+// ---- image layouts: rows of exactly D (64) halfs, the 16-byte chunks of a row XOR-swizzled by a function of the row --
+// The round-2 images padded every row (D + 16 / 72 halfs).  That serves the ds_read_b128 row fragments, but the
+// transposing reads of GC (4 rows x 32 columns per half wave) and the 8-byte e-hat reads of the epilogues were 2-way
+// bank-conflicted, and so were G's row fragments: 37 % of the kernel's LDS cycles were conflict cycles.  These two
+// swizzles make every read pattern of both images conflict-free (tools/lds_conflicts.py models the banks: b128 in four
+// 16-lane groups, b64 / tr_b16 in two 32-lane halves, 64 banks; the G writes of S stay 2-way) and the images are 10 KB
+// smaller.  An offset is in halfs; h / s (the column) must be a multiple of 4.
+template <int D>
+__device__ __forceinline__ int et_off(int r, int h) {
+    constexpr int MASK = (D % 128 == 0) ? 15 : 7;        // D = 64, 192: stay inside an aligned group of eight chunks
+    const int f = (4 * (r & 3) + ((4 - ((r >> 2) & 3)) & 3)) & MASK;
+    return r * D + ((((h >> 3) ^ f) << 3) | (h & 7));
+}
+__device__ __forceinline__ int g_off(int r, int s) {
+    const int f = (r & 3) | ((((r >> 1) ^ (r >> 2)) & 1) << 2);
+    return r * GP + ((((s >> 3) ^ f) << 3) | (s & 7));
+}
+// transposed 32 x 32 x 16 fragment (ge2e_split_gemm.hpp: frag_tr) from a swizzled image: K-rows kb + 8 (lane >> 5) + 0..7 of
+// column cb + (lane & 31)
+template <int D>
+__device__ __forceinline__ h8 frag_tr_et(const _Float16* img, int kb, int cb, int lane) {
+    const int hh = lane >> 5, g2 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int row = kb + 8 * hh + qq, h = cb + 16 * g2 + 4 * pp;
+    const h4 t0 = tr_read4(img + et_off<D>(row, h));
+    const h4 t1 = tr_read4(img + et_off<D>(row + 4, h));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ h8 frag_tr_g(const _Float16* img, int kb, int cb, int lane) {
+    const int hh = lane >> 5, g2 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int row = kb + 8 * hh + qq, sl = cb + 16 * g2 + 4 * pp;
+    const h4 t0 = tr_read4(img + g_off(row, sl));
+    const h4 t1 = tr_read4(img + g_off(row + 4, sl));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // one lane waits; the result travels through an LDS word that is not reused for four waits (there is a
 // workgroup barrier between any two of them), so ONE barrier per wait is enough
 __device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned target, TeamCtl* ctl, int* sh, int& slot) {
@@ -186,8 +221,7 @@ TeamKWs team_layout(int N, int M, int D) {
     L.rt = (L.spm * M + 15) / 16 * 16;
     L.mul_m = (65536 + M - 1) / M;
     L.head_bytes = (unsigned)align_up(sizeof(TeamCtl) + 64 * sizeof(TeamKFlags), 256);
-    const int P = D + 16;
-    const size_t et = (size_t)2 * L.rt * P * 2;
+    const size_t et = (size_t)2 * L.rt * D * 2;
     const size_t xb = team_xb_bytes(L.rt, D);
     const size_t g = team_g_bytes(L.rt, D);
     L.xb_bytes = (unsigned)xb;
@@ -232,7 +266,7 @@ template <int NCH, int MR, int RBT, bool CONTRAST>
 __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
-    constexpr int P = D + 16;             // image pitch: rows 8 banks apart (b128 row reads AND transposing reads)
+    constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
     constexpr unsigned ROWB = D * 4;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
     constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
@@ -442,8 +476,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     do {                                                                                                     \
         const int r_ = 16 * (RB_) + l15;                                                                     \
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                   \
-            gb[(RB_) & 1][s2][0] = frag_row(Gh + r_ * GP + 32 * s2 + 8 * q);                                 \
-            gb[(RB_) & 1][s2][1] = frag_row(Gl + r_ * GP + 32 * s2 + 8 * q);                                 \
+            gb[(RB_) & 1][s2][0] = frag_row(Gh + g_off(r_, 32 * s2 + 8 * q));                                 \
+            gb[(RB_) & 1][s2][1] = frag_row(Gl + g_off(r_, 32 * s2 + 8 * q));                                 \
         }                                                                                                    \
     } while (0)
                 T2_GE_LOAD(0);
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                         h4 eh[NTI], el[NTI];
 #pragma unroll
                         for (int i = 0; i < NTI; ++i) {
-                            const int eo = r * P + min(16 * T2_DT(i), D - 16) + 4 * q;
+                            const int eo = et_off<D>(r, min(16 * T2_DT(i), D - 16) + 4 * q);
                             eh[i] = *reinterpret_cast<const h4*>(ETh + eo);
                             el[i] = *reinterpret_cast<const h4*>(ETl + eo);
                         }
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float sc = lane_get(rs_l, i);
-                    if (dact) put_split4(ETh, ETl, (rbase + i) * P + d4, scale4(rowv[i], sc));
+                    if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(rowv[i], sc));
                 }
 #ifndef GE2E_X_NOSB_A2
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
@@ -639,13 +673,14 @@ _Pragma("unroll")                                                               
         if (have_cur) {
             GE2E_T2_LANE();
             float* const XBk = khX ? XB1 : XB0;
-            const int off0 = l15 * P + 32 * khX * NCH + 8 * q;
+            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
             h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
             f32x4 acc[2] = {acc_zero4(), acc_zero4()};
 #define T2_X_LOAD(T_)                                                                                     \
     do {                                                                                                  \
-        fb[(T_) & 1][0] = frag_row(ETh + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
-        fb[(T_) & 1][1] = frag_row(ETl + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
+        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
+        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
     } while (0)
 #define T2_X_STORE(RB_)                                                                       \
     *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
@@ -700,13 +735,14 @@ _Pragma("unroll")                                                               
         if (have_cur) {
             GE2E_T2_LANE();
             float* const XBk = khX ? XB1 : XB0;
-            const int off0 = l15 * P + 32 * khX * NCH + 8 * q;
+            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
             h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
             f32x4 acc[2] = {acc_zero4(), acc_zero4()};
 #define T2_X_LOAD(T_)                                                                                     \
     do {                                                                                                  \
-        fb[(T_) & 1][0] = frag_row(ETh + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
-        fb[(T_) & 1][1] = frag_row(ETl + off0 + 16 * ((T_) / NCH) * P + 32 * ((T_) % NCH));               \
+        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
+        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
+        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
     } while (0)
 #define T2_X_STORE(RB_)                                                                       \
     *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
@@ -900,7 +936,7 @@ _Pragma("unroll")                                                               
                 if (rv) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
-                        put_split4(Gh, Gl, r * GP + ((sb + 4 * jj) & (NC - 1)),
+                        put_split4(Gh, Gl, g_off(r, (sb + 4 * jj) & (NC - 1)),
                                    make_float4(gv[4 * jj], gv[4 * jj + 1], gv[4 * jj + 2], gv[4 * jj + 3]));
                 }
             }
@@ -940,7 +976,7 @@ _Pragma("unroll")                                                               
             h4 eh[MR], el[MR];
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
-                const int off = (rbase + min(i, M - 1)) * P + min(d4, D - 4);
+                const int off = et_off<D>(rbase + min(i, M - 1), min(d4, D - 4));
                 eh[i] = *reinterpret_cast<const h4*>(ETh + off);
                 el[i] = *reinterpret_cast<const h4*>(ETl + off);
             }
@@ -990,11 +1026,11 @@ _Pragma("unroll")                                                               
                     h8 gf[2][2], ef[2][2][2];     // [set][hi, lo], [set][b][hi, lo]
 #define T2_GC_LOAD(S_)                                                                   \
     do {                                                                                 \
-        gf[(S_) & 1][0] = frag_tr(Gh, GP, 16 * (S_), 32 * kh, lv_);                     \
-        gf[(S_) & 1][1] = frag_tr(Gl, GP, 16 * (S_), 32 * kh, lv_);                     \
+        gf[(S_) & 1][0] = frag_tr_g(Gh, 16 * (S_), 32 * kh, lv_);                        \
+        gf[(S_) & 1][1] = frag_tr_g(Gl, 16 * (S_), 32 * kh, lv_);                        \
         _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
-            ef[(S_) & 1][b][0] = frag_tr(ETh, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
-            ef[(S_) & 1][b][1] = frag_tr(ETl, P, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+            ef[(S_) & 1][b][0] = frag_tr_et<D>(ETh, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+            ef[(S_) & 1][b][1] = frag_tr_et<D>(ETl, 16 * (S_), 64 * sl + 32 * b, lv_);     \
         }                                                                                \
     } while (0)
                     T2_GC_LOAD(0);
