@@ -539,6 +539,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         {   // every load unconditional (out-of-bounds offsets read zeros): a load under an `if` is a phi at the join, and
             // hipcc resolves it with s_waitcnt vmcnt(0) -- a full L2 round trip in front of A2
             GE2E_T2_LANE();
+            // the partial gradients FIRST: F1 needs them right behind A2, the centroid fragments only at the X contraction,
+            // and the memory queue returns in issue order
+            {   // my speaker's partial gradients of prev (first iteration, forward only: out of bounds, zeros); used in F1
+                const unsigned vrow = (dact && have_prev && has_spk && want_grad) ? (unsigned)d4 * 4u : OOB;
+#pragma unroll
+                for (int mm = 1; mm < TEAM; ++mm)
+                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
+            }
             // block (slot tile tX, hi / lo, K-step khX NCH + s) of the fragment-major centroid form, this lane's 16 bytes
             const unsigned oa = have_cur ? XO.chr[buf] + ((unsigned)tX * (4u * NCH) + (unsigned)khX * NCH) * 1024u + (unsigned)lv_ * 16u : OOB;
 #pragma unroll
@@ -548,12 +556,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             }
             cstv = bload4<AUX_L2>(rsX, have_cur && tid < NC ? XO.cst[buf] + (unsigned)tid * 16u : OOB, 0);
             scv = bload4<AUX_L2>(rsX, have_prev && id.member == 0 && tid < TEAM ? XO.sc[pbuf] + (unsigned)tid * 16u : OOB, 0);
-            if (want_grad) {   // my speaker's partial gradients of prev (first iteration: out of bounds, zeros); used in F1
-                const unsigned vrow = (dact && have_prev && has_spk) ? (unsigned)d4 * 4u : OOB;
-#pragma unroll
-                for (int mm = 1; mm < TEAM; ++mm)
-                    part[mm - 1] = bload4<AUX_L2>(rsX, vrow + XO.gc + (unsigned)(((id.member + mm) & (TEAM - 1)) * NC + kslot) * ROWB, 0);
-            }
         }
         GE2E_PROF(9);
 
@@ -568,17 +570,20 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             float eev[MR];
 #pragma unroll
             for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(rowv[i], rowv[i]) : 0.f;
-            wave_sum_to_sgpr<MR>(eev);
-            float ee_l = 0.f;
-            static_for<0, MR>([&](auto ic) { ee_l = lane_put<decltype(ic)::value>(ee_l, eev[decltype(ic)::value]); });
+            // row i's |e|^2 ends in lane scatter_lane(i) of ONE register (ge2e_common.hpp: wave_sums_scatter)
+            const float ee_l = wave_sums_scatter<MR>(eev, lv_);
             float rne_l, ke_l, ne_l;
             unit_stats_bf(ee_l, eps_cos, eps_cos2, rne_l, ke_l, ne_l);
-            if (lv_ < M) *reinterpret_cast<float4*>(RS + (rbase + lv_) * 8) = make_float4(rne_l, ke_l, ee_l, ne_l);
+            {   // the lane that holds row i's scalars writes them: i = 4 (lane & 15) + [0, 2, 1, 3][lane >> 4]
+                const int rho = lv_ >> 4, irow = 4 * (lv_ & 15) + (((rho & 1) << 1) | (rho >> 1));
+                if ((lv_ & 15) < (MR + 3) / 4 && irow < M)
+                    *reinterpret_cast<float4*>(RS + (rbase + irow) * 8) = make_float4(rne_l, ke_l, ee_l, ne_l);
+            }
             const float rs_l = rne_l * kSplitScale;
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
-                    const float sc = lane_get(rs_l, i);
+                    const float sc = lane_get(rs_l, scatter_lane(i));
                     if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(rowv[i], sc));
                 }
 #ifndef GE2E_X_NOSB_A2
