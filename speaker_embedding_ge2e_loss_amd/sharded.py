@@ -1,0 +1,85 @@
+"""Speaker-sharded EXACT GE2E loss: every rank holds the rows of N / G speakers and the loss is the
+single-device loss over all N speakers -- same value, same gradient -- not G independent losses over fewer negatives.
+
+    local centroids  (get_centroids, s3:34-38)                          [n, D]
+    ALL-GATHER       -> every rank has all N centroids                  N D 4 bytes (256 KB at N = 256, D = 256)
+    similarities of the LOCAL rows against all N centroids, leave-one-out centroid on the own column (get_cos_sim, s3:42-80)
+    S = w cos + b, per-row loss (calc_loss, s3:115-127), summed over the local rows
+    backward: ... -> dC [N, D] from the local rows -> REDUCE-SCATTER (sum) -> each rank's own n rows of it -> centroids_bwd
+
+The two collectives are the only exchange; the sum of the ranks' local losses IS GE2ELoss(all N speakers) and every
+rank's gradient is the matching slice of its gradient (tests/test_sharded.py: a 256-speaker batch cut into 2 and 8 shards
+against the single launch).  (w, b) receive each rank's partial gradient: sum them over the ranks (an all-reduce, e.g. the
+trainer's bucket) for the full one.
+
+Built from the differentiable static helpers, whose kernels take as many centroids as speakers (the reference's
+get_cos_sim does, s3:77-78): the local rows are embedded in an (N, M, D) block of zeros, so a rank sweeps N M rows where
+n M would do -- G-fold redundant row work in kernels that are compatibility paths, not the training hot path.  The
+data-parallel path the north star prescribes (whole batches per rank, trainer.py) is unaffected.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """rows [n, D] on every rank -> [G n, D] in rank order; backward = reduce-scatter (sum) of the gradient."""
+
+    @staticmethod
+    def forward(ctx, rows, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(parts, rows.contiguous(), group=group)
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        world, rank = dist.get_world_size(ctx.group), dist.get_rank(ctx.group)
+        grad = grad.contiguous()
+        n = grad.shape[0] // world
+        out = torch.empty_like(grad[:n])
+        try:
+            dist.reduce_scatter(out, list(grad.split(n, dim=0)), op=dist.ReduceOp.SUM, group=ctx.group)
+        except (RuntimeError, NotImplementedError):   # backends without reduce_scatter (gloo): all-reduce, keep the own rows
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
+            out = grad[rank * n:(rank + 1) * n].clone()
+        return out, None
+
+
+def all_gather_rows(rows: torch.Tensor, group: Optional["dist.ProcessGroup"] = None) -> torch.Tensor:
+    return _AllGatherRows.apply(rows, group)
+
+
+def sharded_ge2e_loss(e_local: torch.Tensor, w: torch.Tensor, b: torch.Tensor, rank: int, world: int, *,
+                      gather: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, ops=None,
+                      eps: float = 1e-6, variant: str = "softmax") -> torch.Tensor:
+    """This rank's share of the exact N-speaker loss: ``e_local`` (n, M, D) are the rows of speakers
+    ``rank * n .. rank * n + n - 1`` of the global batch (N = world * n).  Returns the sum of the per-row losses of the
+    LOCAL rows (a scalar that backpropagates into ``e_local``, ``w``, ``b`` and -- through the gather -- into the other
+    ranks' rows); the global loss is the sum of the returns over the ranks.
+
+    ``gather``: [n, D] -> [N, D] in rank order, differentiable (default: RCCL / gloo all-gather whose backward is a
+    reduce-scatter).  ``ops``: an object with the reference's static helpers ``centroids``, ``cos_sim(e, c, eps=)``,
+    ``calc_loss(sim, eps=, variant=)`` (default: this package's HIP ones, ``functional``)."""
+    if ops is None:
+        from . import functional as ops
+    if gather is None:
+        gather = all_gather_rows
+    n, M, D = e_local.shape
+    N = n * world
+    c_local = ops.centroids(e_local)                              # (n, D)
+    C = gather(c_local)                                           # (N, D): everybody's centroids
+    if C.shape[0] != N:
+        raise RuntimeError(f"gather returned {C.shape[0]} centroids for {N} speakers")
+    # the local rows in their global place; the other speakers' rows are zeros (cosine 0, loss masked out below)
+    pad_before = e_local.new_zeros(rank * n, M, D)
+    pad_after = e_local.new_zeros(N - (rank + 1) * n, M, D)
+    e_pad = torch.cat([pad_before, e_local, pad_after], dim=0).contiguous()
+    cos = ops.cos_sim(e_pad, C, eps=eps)                          # (N, M, N); own column: leave-one-out centroid
+    sim = w * cos + b                                             # s3:27
+    _, per = ops.calc_loss(sim, eps=eps, variant=variant)         # (N, M)
+    return per[rank * n:(rank + 1) * n].sum()

@@ -1,0 +1,186 @@
+"""Speaker-sharded exact loss: the sum of the ranks' local losses is the single-device loss over all N
+speakers and every rank's gradient is its slice of that loss's gradient.
+
+CPU: world_size 2 over gloo with the ORACLE's helpers plugged in as ``ops`` (the product helpers have no CPU path) --
+what is under test is the gather / reduce-scatter orchestration and the masking.
+GPU: a 256-speaker batch cut into 2 and 8 shards, run one after the other on the one card through the HIP helpers,
+against the single fused launch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ge2e_oracle as orc
+from speaker_embedding_ge2e_loss_amd import sharded
+
+
+class OracleOps:
+    """The reference's static helpers (s3:34-38, s3:42-80, s3:115-127) as restated by the oracle."""
+
+    @staticmethod
+    def centroids(e):
+        return orc.centroids(e)
+
+    @staticmethod
+    def cos_sim(e, c, eps=orc.SMALL_ERR):
+        return orc.expand_form_cos_sim(e.contiguous(), c, eps)
+
+    @staticmethod
+    def calc_loss(sim, eps=orc.SMALL_ERR, variant="softmax"):
+        per = orc._softmax_rows(sim, eps) if variant == "softmax" else orc._contrast_rows(sim)
+        return per.sum(), per
+
+
+def _global_batch(N=6, M=4, D=16, seed=5):
+    return torch.from_numpy(orc.synth_embeddings((N, M, D), "unit", seed=seed)).float()
+
+
+def _reference(e, w0=10.0, b0=-5.0, variant="softmax"):
+    e = e.clone().requires_grad_(True)
+    w = torch.tensor(w0, requires_grad=True)
+    b = torch.tensor(b0, requires_grad=True)
+    loss = orc.expand_form_loss(e, w, b, variant=variant)[0]
+    loss.backward()
+    return float(loss.detach()), e.grad.numpy(), float(w.grad), float(b.grad)
+
+
+def _worker(rank, world, port, variant, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    e = _global_batch()
+    n = e.shape[0] // world
+    mine = e[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+    w = torch.tensor(10.0, requires_grad=True)
+    b = torch.tensor(-5.0, requires_grad=True)
+    loss = sharded.sharded_ge2e_loss(mine, w, b, rank, world, ops=OracleOps, variant=variant)
+    loss.backward()
+    wb = torch.stack([w.grad, b.grad])
+    dist.all_reduce(wb)                       # (w, b): partial per rank, summed like the trainer's bucket would
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    out.put((rank, float(tot), mine.grad.numpy(), wb.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_two_ranks_gloo_equal_the_unsharded_loss(variant):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    loss, de, dw, db = _reference(_global_batch(), variant=variant)
+    got = np.concatenate([r[2] for r in res], axis=0)
+    for r in res:
+        assert abs(r[1] - loss) <= 2e-5 * abs(loss)
+        assert np.allclose(r[3], [dw, db], rtol=2e-5, atol=2e-6)
+    assert np.allclose(got, de, rtol=2e-5, atol=1e-7), np.abs(got - de).max()
+
+
+def test_single_process_gather_hook():
+    """world 3 emulated in one process: ``gather`` = concatenation of every shard's centroids (autograd's cat backward
+    is the reduce-scatter)."""
+    e = _global_batch(N=6)
+    shards = [e[2 * k:2 * k + 2].clone().requires_grad_(True) for k in range(3)]
+    w = torch.tensor(10.0, requires_grad=True)
+    b = torch.tensor(-5.0, requires_grad=True)
+    cents = [OracleOps.centroids(s) for s in shards]
+    total = sum(sharded.sharded_ge2e_loss(shards[k], w, b, k, 3, ops=OracleOps, gather=lambda c: torch.cat(cents, 0))
+                for k in range(3))
+    total.backward()
+    loss, de, dw, db = _reference(e)
+    assert abs(float(total) - loss) <= 2e-5 * abs(loss)
+    got = np.concatenate([s.grad.numpy() for s in shards], 0)
+    assert np.allclose(got, de, rtol=2e-5, atol=1e-7)
+    assert np.allclose([float(w.grad), float(b.grad)], [dw, db], rtol=2e-5, atol=2e-6)   # db cancels to ~1e-4
+
+
+def test_gather_size_is_checked():
+    e = _global_batch(N=4)[:2].clone()
+    w, b = torch.tensor(10.0), torch.tensor(-5.0)
+    with pytest.raises(RuntimeError, match="centroids"):
+        sharded.sharded_ge2e_loss(e, w, b, 0, 2, ops=OracleOps, gather=lambda c: c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_gpu_shards_equal_the_single_launch(world, variant):
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+
+    N, M, D = 256, 10, 256
+    dev = torch.device("cuda:0")
+    e = torch.from_numpy(orc.synth_embeddings((N, M, D), "unit", seed=77)).float().to(dev)
+    w0, b0 = 10.0, -5.0
+
+    ef = e.clone().requires_grad_(True)
+    wf = torch.tensor(w0, device=dev, requires_grad=True)
+    bf = torch.tensor(b0, device=dev, requires_grad=True)
+    full = GF.ge2e_loss(ef, wf, bf, variant=variant)
+    full.backward()
+
+    n = N // world
+    shards = [e[k * n:(k + 1) * n].clone().requires_grad_(True) for k in range(world)]
+    w = torch.tensor(w0, device=dev, requires_grad=True)
+    b = torch.tensor(b0, device=dev, requires_grad=True)
+    cents = [GF.centroids(s) for s in shards]
+    total = sum(sharded.sharded_ge2e_loss(shards[k], w, b, k, world, gather=lambda c: torch.cat(cents, 0),
+                                          variant=variant) for k in range(world))
+    total.backward()
+    torch.cuda.synchronize()
+
+    assert abs(float(total) - float(full)) <= 2e-5 * abs(float(full)), (float(total), float(full))
+    got = torch.cat([s.grad for s in shards], 0)
+    rel = float((got - ef.grad).norm() / ef.grad.norm())
+    assert rel <= 2e-5, rel
+    assert abs(float(w.grad) - float(wf.grad)) <= 2e-5 * abs(float(wf.grad)) + 1e-6
+    assert abs(float(b.grad) - float(bf.grad)) <= 1e-4      # db cancels to ~1e-3: the suite's absolute bound
+
+
+@pytest.mark.gpu
+def test_gpu_single_rank_nccl_group():
+    """The default gather (all-gather forward, reduce-scatter backward) over RCCL with one rank: world 1 is the plain loss."""
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        dev = torch.device("cuda:0")
+        e = torch.from_numpy(orc.synth_embeddings((16, 5, 64), "unit", seed=3)).float().to(dev)
+        a = e.clone().requires_grad_(True)
+        w = torch.tensor(10.0, device=dev, requires_grad=True)
+        b = torch.tensor(-5.0, device=dev, requires_grad=True)
+        loss = sharded.sharded_ge2e_loss(a, w, b, 0, 1)
+        loss.backward()
+        a2 = e.clone().requires_grad_(True)
+        w2 = torch.tensor(10.0, device=dev, requires_grad=True)
+        b2 = torch.tensor(-5.0, device=dev, requires_grad=True)
+        ref = GF.ge2e_loss(a2, w2, b2)
+        ref.backward()
+        assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref))
+        assert float((a.grad - a2.grad).norm() / a2.grad.norm()) <= 2e-5
+    finally:
+        if own:
+            dist.destroy_process_group()
