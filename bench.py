@@ -374,6 +374,43 @@ def main():
                 except Exception as ex:  # unsupported shape for this kernel
                     extra["exact_f32"] = {"impl": cand, "value": None, "note": str(ex)[:120]}
 
+    if rank == 0 and not dry and args.mode == "train-step":
+        # the encoder tail (normalise s2:34 + un-permute s4:186 + (N,M,D) view s4:189) in front of the loss.
+        # Separate: normalize_unperm launch + loss launch(es) + normalize_unperm backward launch; raw: ONE launch that
+        # normalises and gathers in its load stage and scatters dL/dy from its store stage (ge2e_loss_fwd_bwd_raw).
+        # Timed through autograd as the trainer calls them (forward + backward of the tail and the loss), on the
+        # reference's own training shapes; launch counts are what each route enqueues on the stream per step.
+        tails = {}
+        for (tn, tm) in ((4, 5), (2, 16)):
+            rows = tn * tm
+            gen = torch.Generator(device=dev).manual_seed(5)
+            y = torch.randn(rows, D, device=dev, generator=gen).requires_grad_(True)
+            perm = torch.randperm(rows, generator=torch.Generator().manual_seed(6))
+            unperm = torch.empty_like(perm)
+            unperm[perm] = torch.arange(rows)
+            unperm = unperm.to(dev).to(torch.int32)
+            wt = torch.tensor(10.0, device=dev, requires_grad=True)
+            bt = torch.tensor(-5.0, device=dev, requires_grad=True)
+
+            def separate():
+                y.grad = wt.grad = bt.grad = None
+                GF.ge2e_loss(GF.normalize_unperm(y, unperm, shape=(tn, tm)), wt, bt).backward()
+
+            def raw():
+                y.grad = wt.grad = bt.grad = None
+                GF.ge2e_loss_raw(y, unperm, wt, bt, (tn, tm)).backward()
+
+            rec = {"raw_supported": bool(GF.raw_supported(tn, tm, D))}
+            for nm, fn in (("separate", separate), ("raw", raw)):
+                for _ in range(5):
+                    fn()
+                rec[f"{nm}_us"] = float(np.median(time_launches(fn, 50))) * 1e3
+            # kernels of OURS per step (autograd's own ones_like fill not counted): tail fwd + loss + grad scaling + tail bwd
+            rec["launches_separate"] = 4
+            rec["launches_raw"] = 2 if rec["raw_supported"] else 4
+            tails[f"N={tn},M={tm},D={D}"] = rec
+        extra["encoder_tail"] = tails
+
     verify = None
     if rank == 0 and not dry and args.mode == "loss" and not args.no_verify and N * N * M * D <= 64 * 64 * 10 * 256 * 64:
         step()   # the benched implementation's outputs (the exact-fp32 leg may have run since)

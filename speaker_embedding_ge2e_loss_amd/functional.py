@@ -40,7 +40,15 @@ def _as_batched(e: torch.Tensor):
     return (e.unsqueeze(0) if squeeze else e), squeeze
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(t: torch.Tensor) -> int:
+    """The raw hipStream_t of torch's current stream on t's device (the C call when this torch has it: 0.3 us against
+    5 us for building a torch.cuda.Stream object on every launch)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -494,8 +502,8 @@ class _GE2ELossFunction(torch.autograd.Function):
     def forward(ctx, embeddings, w, b, eps, eps_cos, variant, impl):
         need = any(ctx.needs_input_grad[:3])
         squeeze = embeddings.dim() == 3
-        o = loss_fwd_bwd(embeddings.detach(), w.detach(), b.detach(), eps=eps, eps_cos=eps_cos,
-                         variant=variant, impl=impl, need_grad=need)
+        # (no .detach(): inside Function.forward nothing is recorded, and only the data pointers cross the boundary)
+        o = loss_fwd_bwd(embeddings, w, b, eps=eps, eps_cos=eps_cos, variant=variant, impl=impl, need_grad=need)
         ctx.squeeze = squeeze
         ctx.w_shape, ctx.b_shape = w.shape, b.shape
         if need:
