@@ -294,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     _Float16* const STG = reinterpret_cast<_Float16*>(XB1);        // A: centroid stage [hi, lo][8 slots][D + STGPAD]
     constexpr int SP = D + STGPAD;
 
-    const int N = p.N, M = p.M, NM = N * M;
+    // the metric-shape instantiation (RBT != 0) is launched only with M == MR: row loops lose their `i < M` branches
+    constexpr bool MEX = RBT != 0;
+    const int N = p.N, M = MEX ? MR : p.M, NM = N * M;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     int lv_ = lane;                                                     \
     asm volatile("" : "+v"(lv_));                                       \
     const int l15 = lv_ & 15, q = lv_ >> 4, d4 = 4 * lv_;               \
-    const bool dact = d4 < D;                                           \
+    const bool dact = D == 256 || d4 < D;   /* 64 lanes x 4 columns: every lane has columns at D = 256 */ \
     (void)l15; (void)q; (void)d4; (void)dact
 
 #ifdef GE2E_X_PRIO
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         // a time (184 per iteration and wave); an s_mul / s_add where the value is needed is cheaper
         int wid_o = wid_outer, mem_o = member_outer, tid_o = tid_outer, m_o = m_outer;
         asm volatile("" : "+s"(wid_o), "+s"(mem_o), "+v"(tid_o), "+s"(m_o));
-        const int wid = wid_o, tid = tid_o, lane = tid & 63, M = m_o, NM = N * M;
+        const int wid = wid_o, tid = tid_o, lane = tid & 63, M = MEX ? MR : m_o, NM = N * M;
         TeamId id = id_outer;
         id.member = mem_o;
         const int j0 = id.member * spm;
@@ -1134,7 +1136,7 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
 }
 template <int NCH, int MR>
 static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
-    if (NCH == 4 && MR == 10 && L.rt == 80)   // the metric shape: compile-time trip counts
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10)   // the metric shape: compile-time trip counts, M == MR
         return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
     return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
 }
