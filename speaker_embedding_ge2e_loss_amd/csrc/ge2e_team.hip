@@ -295,8 +295,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     constexpr int SP = D + STGPAD;
 
     // the metric-shape instantiation (RBT != 0) is launched only with M == MR: row loops lose their `i < M` branches
+    // and N == 64 (every member full: 8 speakers, 80 rows), so that the has-a-speaker predicates fold away too
     constexpr bool MEX = RBT != 0;
-    const int N = p.N, M = MEX ? MR : p.M, NM = N * M;
+    const int N = MEX ? 64 : p.N, M = MEX ? MR : p.M, NM = N * M;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
         reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * XO.stride, XO.stride);
 
-    const int spm = L.spm;
+    const int spm = MEX ? 8 : L.spm;
     const int j0 = id.member * spm;                    // first speaker of this member
-    const int my_spm = max(0, min(spm, N - j0));
+    const int my_spm = MEX ? 8 : max(0, min(spm, N - j0));
     const int R_my = my_spm * M;
     const bool has_spk = wid < my_spm;
     const int j = j0 + wid;                            // this wave's speaker (if has_spk)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         TeamId id = id_outer;
         id.member = mem_o;
         const int j0 = id.member * spm;
-        const int my_spm = max(0, min(spm, N - j0));
+        const int my_spm = MEX ? 8 : max(0, min(spm, N - j0));
         const int R_my = my_spm * M;
         const bool has_spk = wid < my_spm;
         const int j = j0 + wid;
@@ -1136,7 +1137,7 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
 }
 template <int NCH, int MR>
 static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
-    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10)   // the metric shape: compile-time trip counts, M == MR
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64)   // the metric shape: compile-time N, M, trip counts
         return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
     return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
 }
