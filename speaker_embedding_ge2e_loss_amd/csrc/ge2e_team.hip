@@ -1069,15 +1069,22 @@ _Pragma("unroll")                                                               
                         // leaves the L2 as a write request of its own)
                         const int l31 = lv_ & 31, h = lv_ >> 5;
                         const unsigned ob = XO.gc + (unsigned)((id.member * NC + 32 * kh + 4 * h) * D + 64 * sl + l31) * 4u;
+                        // One lane offset for all 32 stores, the (register, column half) part in the scalar offset; the four
+                        // registers of the member's own slots -- 32 kh + 8 (member & 3) + (i & 3) + 4 h, they stay in LDS
+                        // (below) -- are skipped by a uniform branch.  (A per-store `own ? OOB : ob + c` was a v_add and a
+                        // v_cndmask per store: 64 VALU instructions per wave and batch behind the contraction.)
+                        const int own_g = kh == (id.member >> 2) ? (id.member & 3) : -1;
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
+                        for (int g = 0; g < 4; ++g) {
+                            if (g != own_g) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                // own slots 8 member .. + 7 = slots 32 kh + 8 (member & 3) + (i & 3) + 4 h stay in LDS (below)
-                                const bool own = kh == (id.member >> 2) && (i >> 2) == (id.member & 3);
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gc[b][i]), rsX,
-                                    own ? OOB : ob + (unsigned)(((i & 3) + 8 * (i >> 2)) * D + 32 * b) * 4u, 0, 0);
+                                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t)
+                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gc[b][4 * g + t]), rsX, ob,
+                                                                              (unsigned)((t + 8 * g) * D + 32 * b) * 4u, 0);
                             }
+                        }
                         if (kh == (id.member >> 2)) {
                             float* const o = OWNP + (4 * h) * D + 64 * sl + l31;
 #define T2_OWN(G_)                                                                                  \
