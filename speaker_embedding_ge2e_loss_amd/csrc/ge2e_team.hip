@@ -381,7 +381,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 #ifdef GE2E_X_PRIO
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // the younger wave of each SIMD
 #endif
-    GE2E_PROF_DECL(13)
+    GE2E_PROF_DECL(20)
+#ifdef GE2E_PROF_A1     // finer view of A1 (tools/profile_phases.py prints slots 14..18)
+#define GE2E_PROF_SUB(i) GE2E_PROF(i)
+#else
+#define GE2E_PROF_SUB(i)
+#endif
     GE2E_T2_LOAD_ROWS(id.team);
     const TeamId id_outer = id;
     int wslot = 0;
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 #pragma unroll
             for (int i = 0; i < MR; ++i)
                 if (i < M) { s.x += rowv[i].x; s.y += rowv[i].y; s.z += rowv[i].z; s.w += rowv[i].w; }
+            GE2E_PROF_SUB(14);
             const float4 c = scale4(s, inv_m);
             float sqs[2] = {dot4(c, c), dot4(s, s)};
             wave_sum_to_sgpr<2>(sqs);
@@ -448,7 +454,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             bstore4(rsX, lane == 0 ? XO.cst[buf] + (unsigned)kslot * 16u : OOB,
                                     make_float4(rn, kap, has_spk ? fM * nc : 0.f, has_spk ? ss : 0.f));
         }
+        GE2E_PROF_SUB(15);
         __syncthreads();
+        GE2E_PROF_SUB(16);
         if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d), gathered
             // by the transposing LDS read (4 slots x 16 columns per 16 lanes, twice); whole waves only (2 D % 64 == 0)
             const int hl = tid >= D, d = tid - hl * D;
@@ -459,7 +467,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             bstore4(rsX, XO.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, __builtin_bit_cast(float4, v));
         }
         // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
+        GE2E_PROF_SUB(17);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GE2E_PROF_SUB(18);
         __syncthreads();
         if (tid == 0) {
             if (have_prev) add_agent(&fl->c2, 1u);
@@ -1111,7 +1121,8 @@ _Pragma("unroll")                                                               
 #endif
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    GE2E_PROF_FLUSH(13)
+    GE2E_PROF_FLUSH(20)
+#undef GE2E_PROF_SUB
 #undef GE2E_T2_LOAD_ROWS
 #undef GE2E_T2_LANE
 #undef GE2E_T2_CONSTS

@@ -32,7 +32,9 @@ PHASES = {
               "X tail: slot scalars -> LDS, barrier", "S softmax, G images + barrier",
               "F1 KJ(prev) + barrier", "dE(prev) stores, scalars out",
               "GC partial gC + publish", "-", "requests: centroid fragments, partial gradients", "GE(prev)", "X contraction",
-              "F2 member scalars, KJP(cur)"],
+              "F2 member scalars, KJP(cur)", "-",
+              "A1a (-DGE2E_PROF_A1) wait for the rows (= the memory queue) + speaker sum", "A1b centroid, stores, stage",
+              "A1c barrier", "A1d k-group form stores", "A1e drain (vmcnt 0)"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
