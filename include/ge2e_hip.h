@@ -114,7 +114,11 @@ int ge2e_loss_fwd_bwd_raw(const float* Y, const int* src, int B, int N, int M, i
 
 /* GE2ELoss.get_cos_sim (s3:42-80): cos [B][N][M][N], leave-one-out centroid on
  * the own-speaker column, eps added to every entry.  Forward-only consumer:
- * s5_eval_model.py:42-44. */
+ * s5_eval_model.py:42-44.
+ * Workspace: ge2e_cos_sim_workspace_bytes(B, N, M, D).  With it, shapes the tiled kernel takes (N >= 16, D % 64 == 0) run
+ * the N x (N M) x D contraction on the matrix cores (split-fp16 x3, fp32 accumulate: cosines to ~1e-6); with the smaller
+ * ge2e_workspace_bytes(.., GE2E_IMPL_GENERIC) of ABI 1's rule, or any other shape, the exact-fp32 VALU kernel runs. */
+size_t ge2e_cos_sim_workspace_bytes(int B, int N, int M, int D);
 int ge2e_cos_sim(const float* E, int B, int N, int M, int D,
                  float eps_cos, float eps, float* cos,
                  void* workspace, size_t workspace_bytes, void* stream);

@@ -37,6 +37,7 @@ PROTOTYPES = {
                                         C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ge2e_cos_sim": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp,
                                _fp, C.c_size_t, _fp]),
+    "ge2e_cos_sim_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ge2e_cos_sim_centroids": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "ge2e_calc_loss": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp]),
     "ge2e_selftest_split_gemm": (C.c_int, [_fp] * 7),

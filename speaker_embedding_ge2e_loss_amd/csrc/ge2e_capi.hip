@@ -171,12 +171,32 @@ int ge2e_loss_fwd_bwd_raw(const float* Y, const int* src, int B, int N, int M, i
 }
 
 // Forward-only similarity matrix; w and b are not applied (s5:44 applies its own).
+// get_cos_sim runs on the matrix cores (TILED's preparation pass + split-fp16 similarity contraction + a row pass for the
+// leave-one-out column) where that kernel takes the shape and the contraction is big enough to pay for three launches;
+// tiny shapes (the reference's N = 2..6) stay on the exact-fp32 VALU kernel.
+static bool cos_on_mfma(int N, int M, int D) { return N >= 16 && tiled_supports(N, M, D); }
+
+size_t ge2e_cos_sim_workspace_bytes(int B, int N, int M, int D) {
+    if (!shape_ok(B, N, M, D)) return 0;
+    const size_t g = generic_workspace_bytes(B, N, M, D);
+    const size_t t = cos_on_mfma(N, M, D) ? tiled_workspace_bytes(B, N, M, D) : 0;
+    return g > t ? g : t;
+}
+
 int ge2e_cos_sim(const float* E, int B, int N, int M, int D, float eps_cos, float eps, float* cos,
                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!E || !cos) return GE2E_ERR_NULL;
     Problem p{};
     p.E = E; p.w = nullptr; p.b = nullptr; p.w_imm = 1.0f; p.b_imm = 0.0f; p.cos_out = cos;
     p.B = B; p.N = N; p.M = M; p.D = D; p.variant = GE2E_VARIANT_SOFTMAX; p.eps_cos = eps_cos; p.eps = eps;
+    // (a caller that sized the workspace for the VALU kernel only -- ge2e_workspace_bytes(.., GE2E_IMPL_GENERIC), ABI 1's
+    // rule -- gets the VALU kernel)
+    if (shape_ok(B, N, M, D) && cos_on_mfma(N, M, D) && workspace && workspace_bytes >= tiled_workspace_bytes(B, N, M, D) &&
+        !((uintptr_t)workspace & 255) && !((uintptr_t)E & 15)) {
+        p.ws = (float*)workspace;
+        p.log_eps = eps > 0.f ? logf(eps) : -INFINITY;
+        return (int)launch_tiled_cos(p, (hipStream_t)stream);
+    }
     return run(p, GE2E_IMPL_GENERIC, workspace, workspace_bytes, stream);
 }
 

@@ -716,6 +716,30 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
 
 // ---------------------------------------------------------------------------------------------
 // k_reduce: one workgroup per batch, fixed-order sums of the per-row loss / dw / db.
+// get_cos_sim's output from the similarity contraction (s3:42-80): cos[r][k] = X[r][k] + eps, the own column replaced by the
+// cosine with the leave-one-out centroid, which follows from X's own column and the row / speaker scalars of the
+// preparation pass exactly as in the row kernels above.  One wave per row, lanes along the slots: coalesced both ways.
+__global__ __launch_bounds__(256) void ge2e_tiled_cos(Problem p, TiledWs L) {
+    const int lane = threadIdx.x & 63;
+    const size_t gr = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // global row
+    const int N = p.N, M = p.M, NM = N * M, npad = L.npad;
+    if (gr >= (size_t)p.B * NM) return;
+    const int bi = (int)(gr / NM), r = (int)(gr - (size_t)bi * NM), j = r / M;
+    const float* X = p.ws + L.x + ((size_t)bi * NM + r) * npad;
+    const float4 rst = *reinterpret_cast<const float4*>(p.ws + L.rst + gr * 4);                   // rne ke ee
+    const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);  // rn kap |s| |s|^2
+    const float inv_m1 = 1.0f / (float)(M - 1);
+    const float rne = rst.x, ee = rst.z;
+    const float es = X[j] * cs.z / rne;
+    const float eu = (es - ee) * inv_m1;
+    const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+    float rnu, ku;
+    unit_stats_fast(uu, p.eps_cos, rnu, ku);
+    const float cosd = eu * rne * rnu;
+    float* out = p.cos_out + gr * N;
+    for (int k = lane; k < N; k += 64) out[k] = (k == j ? cosd : X[k]) + p.eps;
+}
+
 __global__ __launch_bounds__(256) void ge2e_tiled_reduce(Problem p, TiledWs L) {
     __shared__ float red[3][256];
     const int bi = blockIdx.x, tid = threadIdx.x, NM = p.N * p.M;
@@ -814,6 +838,27 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     }
     else   // forward only: nothing ran after k_rows that could carry the sums
         hipLaunchKernelGGL(ge2e_tiled_reduce, dim3((unsigned)p.B), dim3(256), 0, stream, p, L);
+    return hipGetLastError();
+}
+
+// Forward half only, for ge2e_cos_sim: preparation, similarity contraction on the matrix cores, cos output.
+hipError_t launch_tiled_cos(const Problem& p, hipStream_t stream) {
+    const TiledWs L = tiled_layout(p.B, p.N, p.M, p.D);
+    const int NM = p.N * p.M;
+    typedef GemmCfg<128, 128> C1;
+    typedef GemmCfg<256, 256> C2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
+    const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= 192;
+    hipLaunchKernelGGL(ge2e_tiled_prep, dim3((unsigned)((p.B * p.N + 3) / 4)), dim3(256), 0, stream, p, L);
+    if (big_sim)
+        hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    else
+        hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
+    hipLaunchKernelGGL(ge2e_tiled_cos, dim3((unsigned)(((size_t)p.B * NM + 3) / 4)), dim3(256), 0, stream, p, L);
     return hipGetLastError();
 }
 

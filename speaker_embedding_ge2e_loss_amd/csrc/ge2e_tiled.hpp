@@ -13,5 +13,6 @@ bool tiled_supports(int N, int M, int D);
 TiledWs tiled_layout(int B, int N, int M, int D);
 size_t tiled_workspace_bytes(int B, int N, int M, int D);
 hipError_t launch_tiled(const Problem& p, hipStream_t stream);
+hipError_t launch_tiled_cos(const Problem& p, hipStream_t stream);   // p.cos_out = get_cos_sim(E): forward half only
 
 }  // namespace ge2e

@@ -173,7 +173,7 @@ def _cos_forward(e4: torch.Tensor, c3: Optional[torch.Tensor], eps: float, eps_c
                                               _stream_ptr(e4))
             _lib.check(code, "ge2e_cos_sim_centroids")
         else:
-            ws = alloc_workspace(lib.ge2e_workspace_bytes(B, N, M, D, 0, _lib.IMPL_GENERIC), e4.device)
+            ws = alloc_workspace(lib.ge2e_cos_sim_workspace_bytes(B, N, M, D), e4.device)   # MFMA route where it exists
             code = lib.ge2e_cos_sim(e4.data_ptr(), B, N, M, D, eps_cos, eps, cos.data_ptr(), ws.data_ptr(), ws.numel(),
                                     _stream_ptr(e4))
             _lib.check(code, "ge2e_cos_sim")
@@ -228,8 +228,10 @@ class _UttCentroidsFunction(torch.autograd.Function):
 
 class _CosSimFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e4, c3, eps, eps_cos):
-        cos = _cos_forward(e4, c3, eps, eps_cos)
+    def forward(ctx, e4, c3, eps, eps_cos, own=False):
+        # own: c3 IS get_centroids(e4) (what every caller of the reference passes) -- the forward then takes ge2e_cos_sim,
+        # whose contraction runs on the matrix cores for the shapes the tiled kernel accepts; c3 is kept for the backward
+        cos = _cos_forward(e4, None if own else c3, eps, eps_cos)
         ctx.save_for_backward(e4, c3, cos)
         ctx.eps, ctx.eps_cos = eps, eps_cos
         return cos
@@ -249,7 +251,7 @@ class _CosSimFunction(torch.autograd.Function):
                                         ctx.eps_cos, ctx.eps, dE.data_ptr(), dC.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _stream_ptr(e4))
         _lib.check(code, "ge2e_cos_sim_bwd")
-        return dE, dC, None, None
+        return dE, dC, None, None, None
 
 
 class _CalcLossFunction(torch.autograd.Function):
@@ -294,14 +296,15 @@ def cos_sim(embeddings: torch.Tensor, centroids: torch.Tensor | None = None, *, 
     _require_cuda(embeddings, "embeddings")
     e4, squeeze = _as_batched(embeddings)
     B, N, M, D = e4.shape
-    if centroids is None:
+    own = centroids is None
+    if own:
         centroids = _CentroidsFunction.apply(e4)
     _require_cuda(centroids, "centroids")
     c3 = centroids.to(torch.float32).reshape(B, -1, D).contiguous()
     if c3.shape[1] != N:
         # s3:77-78 indexes cos_diff[j, :, j] for every speaker j: the reference needs as many centroids as speakers
         raise RuntimeError(f"get_cos_sim: {c3.shape[1]} centroids for {N} speakers")
-    cos = _CosSimFunction.apply(e4, c3, float(eps), float(eps_cos))
+    cos = _CosSimFunction.apply(e4, c3, float(eps), float(eps_cos), own)
     return cos[0] if squeeze else cos
 
 

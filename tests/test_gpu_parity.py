@@ -348,3 +348,22 @@ def test_get_cos_sim_uses_the_callers_centroids(GF):
         assert np.allclose(own.cpu().numpy(), ref_own, atol=3e-6)
     with pytest.raises(RuntimeError):
         GE2ELoss.get_cos_sim(e.detach(), torch.zeros(3, 256, device="cuda:0"), hp)   # 3 centroids for 64 speakers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 10, 256), (256, 10, 256), (17, 3, 64), (40, 5, 192), (16, 2, 128)])
+def test_cos_sim_on_the_matrix_cores(GF, shape):
+    """ge2e_cos_sim takes the tiled kernel's similarity contraction (split-fp16 MFMA) where the shape allows: against the
+    fp32 VALU kernel fed with the same centroids, and against the oracle's expand form (s3:42-80)."""
+    N, M, D = shape
+    E = orc.synth_embeddings((2, N, M, D), "unit", seed=41 + N)
+    e = torch.as_tensor(E, device="cuda:0")
+    cos = GF.cos_sim(e)                                       # MFMA route (N >= 16, D % 64 == 0)
+    ref_valu = GF.cos_sim(e, GF.centroids(e))                 # exact-fp32 VALU kernel, caller's centroids
+    torch.cuda.synchronize()
+    assert cos.shape == (2, N, M, N) and bool(torch.isfinite(cos).all())
+    assert float((cos - ref_valu).abs().max()) < 5e-6
+    for bi in range(2):
+        t = torch.as_tensor(E[bi])
+        ref = orc.expand_form_cos_sim(t, orc.centroids(t)).numpy()
+        assert np.abs(cos[bi].cpu().numpy() - ref).max() < 5e-6
