@@ -975,6 +975,25 @@ _Pragma("unroll")                                                               
         for (int st2_ = 0; st2_ < 2; ++st2_) {
         if ((st2_ == 0) == (wid < 4)) {
 #endif
+        // GE's centroid fragments (k-group form, published in this iteration's A1) are requested HERE, in front of the two
+        // phases that issue no memory instruction (F2 is vector work, GC's contraction reads LDS): the address path is
+        // idle now and saturated behind GC's contraction, where these eight 1-KB loads per wave used to stand in front of
+        // the read-done poll and the 32 partial-gradient stores.  (32 registers live through F2 and GC.)
+#define T2_GA_LOAD()                                                                                                      \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NTI; ++i) {                                                                 \
+            const int dt = T2_DT(i);                                                                                      \
+            const bool on = dt < NT;                                                                                      \
+            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
+                const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u; \
+                ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);                                                    \
+                ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);                                \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+#ifndef GE2E_X_GA_LATE
+        if (want_grad) { GE2E_T2_LANE(); T2_GA_LOAD(); }
+#endif
         // ===== F2: member scalars out; KJP'_j of cur (wave-local: it stays in registers until the next F1) ==========
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
@@ -1019,18 +1038,6 @@ _Pragma("unroll")                                                               
             // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
             // dead (requested before it they cost 32 more registers under the accumulators and the allocator spilled
             // them); the answers land under the read-done wait and the partial-gradient stores
-#define T2_GA_LOAD()                                                                                                      \
-    do {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NTI; ++i) {                                                                 \
-            const int dt = T2_DT(i);                                                                                      \
-            const bool on = dt < NT;                                                                                      \
-            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
-                const unsigned o = XO.cht[buf] + (unsigned)(4 * s2 + q) * (2u * D * 16u) + (unsigned)(16 * dt + l15) * 16u; \
-                ga[i][s2][0] = bload_h8<AUX_L2>(rsX, on ? o : OOB, 0);                                                    \
-                ga[i][s2][1] = bload_h8<AUX_L2>(rsX, on ? o + (unsigned)D * 16u : OOB, 0);                                \
-            }                                                                                                             \
-        }                                                                                                                 \
-    } while (0)
             // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
             {
                 GE2E_T2_LANE();
@@ -1064,7 +1071,9 @@ _Pragma("unroll")                                                               
                         }
                     }
 #undef T2_GC_LOAD
+#ifdef GE2E_X_GA_LATE
                     T2_GA_LOAD();
+#endif
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -1110,7 +1119,9 @@ _Pragma("unroll")                                                               
                         }
                     }
                 } else {
+#ifdef GE2E_X_GA_LATE
                     T2_GA_LOAD();
+#endif
                 }
             }
 #undef T2_GA_LOAD
