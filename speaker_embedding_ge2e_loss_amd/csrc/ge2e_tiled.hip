@@ -188,6 +188,10 @@ __device__ __forceinline__ void gemm_zero(f32x16 (&acc)[C::A2][C::B2]) {
 
 // ---------------------------------------------------------------------------------------------
 // k_prep: one wave per speaker.  D <= 1024: four float4 per lane cover a row.
+// RM > 0: the speaker's rows (M <= RM, D <= 256 NP) stay in registers between the speaker sum and the row pass -- E is
+// read from memory ONCE (the generic form reads every row twice, and with a few hundred KB of rows in flight per CU the
+// second read misses the L2: FETCH_SIZE of this kernel was twice the size of E).
+template <int RM, int NP>
 __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave = (batch, speaker)
@@ -204,23 +208,36 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     float* CST = p.ws + L.cst + ((size_t)bi * N + j) * 4;
     float* RST = p.ws + L.rst + ((size_t)bi * N + j) * M * 4;
     const float fM = (float)M;
-    const int npass = (D + 255) >> 8;
+    constexpr int NPC = RM > 0 ? NP : 4;                  // float4 chunks of a row per lane
+    const int npass = RM > 0 ? NP : (D + 255) >> 8;
 
-    float4 s[4];
+    float4 s[NPC];
+    float4 rows[RM > 0 ? RM : 1][NPC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = 0; i < M; ++i)
+    for (int c = 0; c < NPC; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RM > 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int d = 256 * c + 4 * lane;
-            if (c < npass && d < D) {
-                const float4 v = *reinterpret_cast<const float4*>(E + (size_t)i * D + d);
-                s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+        for (int i = 0; i < (RM > 0 ? RM : 1); ++i)
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) {
+                const int d = 256 * c + 4 * lane;
+                rows[i][c] = (i < M && d < D) ? *reinterpret_cast<const float4*>(E + (size_t)i * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s[c].x += rows[i][c].x; s[c].y += rows[i][c].y; s[c].z += rows[i][c].z; s[c].w += rows[i][c].w;
             }
-        }
+    } else {
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) {
+                const int d = 256 * c + 4 * lane;
+                if (c < npass && d < D) {
+                    const float4 v = *reinterpret_cast<const float4*>(E + (size_t)i * D + d);
+                    s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                }
+            }
+    }
     float sq = 0.f, ss = 0.f;   // |c|^2 with c = s / M formed first, like the reference; |s|^2 for the row stats
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NPC; ++c) {
         const float4 cc = make_float4(s[c].x / fM, s[c].y / fM, s[c].z / fM, s[c].w / fM);
         sq += dot4(cc, cc);
         ss += dot4(s[c], s[c]);
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     float rn, kap;
     unit_stats(sq, p.eps_cos, rn, kap);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NPC; ++c) {
         const int d = 256 * c + 4 * lane;
         if (c < npass && d < D) {
             const float4 ch = make_float4(s[c].x / fM * rn, s[c].y / fM * rn, s[c].z / fM * rn, s[c].w / fM * rn);
@@ -243,22 +260,16 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     }
     if (lane == 0) *reinterpret_cast<float4*>(CST) = make_float4(rn, kap, fM / rn, ss);
     // rows: 1/|e| and the e-hat images
-    for (int i = 0; i < M; ++i) {
-        float4 v[4];
+    auto row_out = [&](int i, const float4 (&v)[NPC]) {
         float ee = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int d = 256 * c + 4 * lane;
-            v[c] = (c < npass && d < D) ? *reinterpret_cast<const float4*>(E + (size_t)i * D + d)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            ee += dot4(v[c], v[c]);
-        }
+        for (int c = 0; c < NPC; ++c) ee += dot4(v[c], v[c]);
         ee = wave_sum(ee);
         float rne, ke;
         unit_stats_fast(ee, p.eps_cos, rne, ke);
         const size_t r = (size_t)j * M + i;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NPC; ++c) {
             const int d = 256 * c + 4 * lane;
             if (c < npass && d < D) {
                 h4 hi, lo;
@@ -268,7 +279,31 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
             }
         }
         if (lane == 0) *reinterpret_cast<float4*>(RST + (size_t)i * 4) = make_float4(rne, ke, ee, 0.f);
+    };
+    if (RM > 0) {
+#pragma unroll
+        for (int i = 0; i < (RM > 0 ? RM : 1); ++i)
+            if (i < M) row_out(i, rows[i]);
+    } else {
+        for (int i = 0; i < M; ++i) {
+            float4 v[NPC];
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) {
+                const int d = 256 * c + 4 * lane;
+                v[c] = (c < npass && d < D) ? *reinterpret_cast<const float4*>(E + (size_t)i * D + d)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            row_out(i, v);
+        }
     }
+}
+// the instantiation for a shape: rows in registers when M <= 10 and D <= 768 (40 / 80 / 120 row registers per lane)
+static void launch_prep(const Problem& p, const TiledWs& L, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.B * p.N + 3) / 4)), block(256);
+    if (p.M <= 10 && p.D <= 256) hipLaunchKernelGGL((ge2e_tiled_prep<10, 1>), grid, block, 0, stream, p, L);
+    else if (p.M <= 10 && p.D <= 512) hipLaunchKernelGGL((ge2e_tiled_prep<10, 2>), grid, block, 0, stream, p, L);
+    else if (p.M <= 10 && p.D <= 768) hipLaunchKernelGGL((ge2e_tiled_prep<10, 3>), grid, block, 0, stream, p, L);
+    else hipLaunchKernelGGL((ge2e_tiled_prep<0, 4>), grid, block, 0, stream, p, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -816,7 +851,7 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= fill;
     const bool big_gc = p.N >= 256 && p.D >= 256 && (unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) >= fill;
     const bool big_ge = NM >= 256 && p.D >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256) >= fill;
-    hipLaunchKernelGGL(ge2e_tiled_prep, dim3(spk_blocks), dim3(256), 0, stream, p, L);
+    launch_prep(p, L, stream);
     if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
@@ -853,7 +888,7 @@ hipError_t launch_tiled_cos(const Problem& p, hipStream_t stream) {
     if (e != hipSuccess) return e;
     auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
     const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= 192;
-    hipLaunchKernelGGL(ge2e_tiled_prep, dim3((unsigned)((p.B * p.N + 3) / 4)), dim3(256), 0, stream, p, L);
+    launch_prep(p, L, stream);
     if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
