@@ -306,6 +306,19 @@ static void launch_prep(const Problem& p, const TiledWs& L, hipStream_t stream) 
     else hipLaunchKernelGGL((ge2e_tiled_prep<0, 4>), grid, block, 0, stream, p, L);
 }
 
+// Workgroups go to the XCDs round-robin (workgroup b runs on XCD b % 8), each XCD with an L2 of its own.  Tiles are
+// numbered batch-major with the tiles of one batch adjacent, so in launch order a batch's tiles -- which share an operand
+// (the centroid planes in k_sim / k_ge) -- land on eight different L2s and the shared operand is fetched eight times.
+// This gives the workgroups of ONE XCD a contiguous range of tile numbers instead.
+__device__ __forceinline__ int xcd_major_tile(unsigned b, unsigned grid) {
+#ifdef GE2E_X_TILED_NO_XCD_MAP
+    return (int)b;
+#else
+    const unsigned per = grid / 8;
+    return b < per * 8 ? (int)((b % 8) * per + b / 8) : (int)b;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per TM x TN tile (both operands K-contiguous).
 template <class C>
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M;
     const int rt = (NM + C::TM - 1) / C::TM, ct = (N + C::TN - 1) / C::TN;
-    int t = blockIdx.x;
+    int t = xcd_major_tile(blockIdx.x, gridDim.x);
     const int kt = t % ct; t /= ct;
     const int rtile = t % rt;
     const int bi = t / rt;
@@ -591,7 +604,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M, npad = L.npad;
     const int dtiles = (D + C::TN - 1) / C::TN, ct = (N + C::TM - 1) / C::TM;
-    int t = blockIdx.x;
+    int t = xcd_major_tile(blockIdx.x, gridDim.x);
     const int dt = t % dtiles; t /= dtiles;
     const int kt = t % ct;
     const int bi = t / ct;
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
     const int dtiles = (D + C::TN - 1) / C::TN, rt = (NM + C::TM - 1) / C::TM;
-    int t = blockIdx.x;
+    int t = xcd_major_tile(blockIdx.x, gridDim.x);
     const int dt = t % dtiles; t /= dtiles;
     const int rtile = t % rt;
     const int bi = t / rt;
