@@ -1,5 +1,7 @@
 """Seeded random shapes through impl="auto" (and every implementation that accepts the shape) against the fp64 closed
 form: whatever AUTO resolves to -- wave, team, fused_split, tiled, generic -- has to be right at shapes nobody tuned for."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -33,11 +35,21 @@ def cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", cases(48, seed=2024), ids=lambda c: f"B{c[0]}_N{c[1]}_M{c[2]}_D{c[3]}_{c[4][0]}")
+# (GE2E_FUZZ_SEED / GE2E_FUZZ_N: a longer one-off soak with other shapes; the committed default is what the suite runs)
+@pytest.mark.parametrize("case", cases(int(os.environ.get("GE2E_FUZZ_N", "48")), seed=int(os.environ.get("GE2E_FUZZ_SEED", "2024"))), ids=lambda c: f"B{c[0]}_N{c[1]}_M{c[2]}_D{c[3]}_{c[4][0]}")
 def test_random_shapes(GF, case):
     B, N, M, D, variant, w, b = case
     E = orc.synth_embeddings((B, N, M, D), "raw" if (N + M) % 3 == 0 else "unit", seed=B * 7 + N)
     ref = orc.closed_form(E, w, b, variant=variant)
+    if variant == "contrast":
+        # eq. 7's max over the other speakers is not smooth: where the two largest similarities of a row are closer than
+        # fp32 resolves, fp32 and fp64 may pick different speakers and the row's gradient moves to another centroid
+        S = w * np.asarray(ref["cos"], np.float64) + b
+        jj = np.arange(N)
+        S[:, jj, :, jj] = -np.inf
+        top2 = np.sort(S, axis=-1)[..., -2:]
+        if N > 2 and float((top2[..., 1] - top2[..., 0]).min()) < 5e-6 * max(1.0, float(np.abs(top2[..., 1]).max())):
+            pytest.skip("contrast: a row's two largest similarities tie within fp32 resolution")
     seen = set()
     for impl in impls_for(GF, B, N, M, D, variant):
         resolved = GF.resolve_impl(B, N, M, D, variant, impl)

@@ -65,15 +65,19 @@ def check(o, ref, impl, what=""):
     loss_ref = np.asarray(ref["loss"], np.float64)
     # loss is a sum of NM terms of size ~|S|: fp32 noise floor scales with that, not with |loss|
     floor = 3e-7 * np.abs(np.asarray(ref["per"], np.float64)).sum(axis=(-1, -2))
-    assert np.all(np.abs(o["loss"] - loss_ref) <= lt * np.abs(loss_ref) + floor + 1e-6), \
+    nm = int(np.prod(np.asarray(ref["per"]).shape[-2:]))   # rows per batch: an absolute fp32 floor per row (log(1 + tiny) at N = 1)
+    assert np.all(np.abs(o["loss"] - loss_ref) <= lt * np.abs(loss_ref) + floor + 1e-6 + 2e-7 * nm), \
         f"{what} loss {o['loss']} vs {loss_ref}"
     assert np.allclose(o["per"], ref["per"], rtol=20 * lt, atol=2e-5), f"{what} per"
     scale = max(1.0, float(np.abs(ref["dE"]).max()))
-    assert rel_fro(o["dE"], ref["dE"]) <= gt, f"{what} dE rel-fro {rel_fro(o['dE'], ref['dE'])}"
+    # (a gradient that vanishes -- one speaker: p_jj = 1 - O(eps) -- is held to an absolute bound instead)
+    assert rel_fro(o["dE"], ref["dE"]) <= gt or np.abs(o["dE"] - ref["dE"]).max() <= 1e-8, \
+        f"{what} dE rel-fro {rel_fro(o['dE'], ref['dE'])}"
     assert np.abs(o["dE"] - ref["dE"]).max() <= 4 * gt * scale, f"{what} dE max-abs"
     dw_ref = np.asarray(ref["dw"], np.float64)
-    assert np.all(np.abs(o["dw"] - dw_ref) <= wt * np.abs(dw_ref) + 1e-5), f"{what} dw {o['dw']} vs {dw_ref}"
-    assert np.allclose(o["db"], ref["db"], atol=1e-4), f"{what} db"
+    # dw = sum G (cos + eps) cancels when the rows' terms have both signs: an absolute floor per row beside the relative bound
+    assert np.all(np.abs(o["dw"] - dw_ref) <= wt * np.abs(dw_ref) + 1e-5 + 1e-7 * nm), f"{what} dw {o['dw']} vs {dw_ref}"
+    assert np.allclose(o["db"], ref["db"], atol=1e-4 + 3e-7 * nm), f"{what} db"   # db cancels row by row: an fp32 floor per row
 
 
 @pytest.mark.parametrize("name", golden_names())
