@@ -1,0 +1,54 @@
+"""One-off soak: random shapes the team kernel accepts, many batches per launch (uneven members, partial last rounds, both
+variants), against the one-workgroup-per-batch kernel on the same inputs.  Usage: python tools/soak_team_shapes.py [seed] [n]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from speaker_embedding_ge2e_loss_amd import functional as GF  # noqa: E402
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    bad = 0
+    done = 0
+    while done < n:
+        N = int(rng.integers(2, 65)); M = int(rng.integers(2, 17)); D = int(rng.choice([64, 128, 192, 256]))
+        B = int(rng.integers(1, 700))
+        variant = "contrast" if rng.random() < 0.25 else "softmax"
+        if B * N * M * D > 3e8:
+            continue
+        try:
+            if GF.resolve_impl(B, N, M, D, variant, "team") != "team" or GF.resolve_impl(B, N, M, D, variant, "fused_split") != "fused_split":
+                continue
+        except Exception:
+            continue
+        done += 1
+        g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+        e = torch.randn(B, N, M, D, device=dev, generator=g)
+        if rng.random() < 0.5:
+            e = e / e.norm(dim=-1, keepdim=True)
+        w = torch.tensor(float(rng.uniform(-3, 14)), device=dev); b = torch.tensor(float(rng.uniform(-6, 3)), device=dev)
+        a = GF.loss_fwd_bwd(e, w, b, variant=variant, impl="team")
+        r = GF.loss_fwd_bwd(e, w, b, variant=variant, impl="fused_split")
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(a.dE).all()) and bool(torch.isfinite(a.loss).all())
+        lerr = float(((a.loss - r.loss).abs() / (r.loss.abs() + 1e-3)).max())
+        num = (a.dE - r.dE).flatten(1).norm(dim=1); den = r.dE.flatten(1).norm(dim=1) + 1e-12
+        derr = float((num / den).max())
+        # contrast: an argmax tie within fp32 resolution may resolve differently in the two kernels (one row's gradient)
+        lim = 1e-5 if variant == "softmax" else 5e-2
+        flag = "" if (ok and lerr < 2e-5 and derr < lim) else "   <-- CHECK"
+        bad += bool(flag)
+        print(f"B={B:4d} N={N:2d} M={M:2d} D={D:3d} {variant:8s} w={float(w):6.2f}: loss rel {lerr:.1e}  dE rel-fro (worst batch) {derr:.1e}{flag}", flush=True)
+    print(f"{done} shapes, {bad} to check")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
