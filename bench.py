@@ -354,6 +354,17 @@ def main():
         for _ in range(10):
             module_step()
         extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+        # the same step captured once in a HIP graph and replayed (graphed.GraphedLossStep): the host work of the eager
+        # module path -- Python, autograd dispatch, allocator -- leaves the loop, the device operations stay
+        try:
+            from speaker_embedding_ge2e_loss_amd.graphed import GraphedLossStep
+            gstep = GraphedLossStep(GE2ELoss(HParams(device=dev), variant=variant, impl=args.impl), (N, M, D))
+            gstep(E[0])
+            torch.cuda.synchronize()
+            extra["latency_module_graph_b1_us"] = float(np.median(time_launches(lambda: gstep(), 100))) * 1e3
+        except Exception as ex:   # capture unsupported by this torch / runtime
+            extra["latency_module_graph_b1_us"] = None
+            extra["latency_module_graph_note"] = str(ex)[:160]
 
         # the exact-fp32 kernel beside the split-fp16 one (same workload; fewer steps)
         if impl in SPLIT_IMPLS and world == 1:

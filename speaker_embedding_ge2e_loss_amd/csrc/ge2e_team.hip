@@ -1140,6 +1140,16 @@ _Pragma("unroll")                                                               
 }
 
 // ---------------------------------------------------------------------------------------------
+// zeroes the control block at the head of the workspace (n16 16-byte pieces); one_word >= 0: that 32-bit word becomes 1
+__global__ __launch_bounds__(256) void team_zero_head(uint4* head, int n16, int one_word) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (one_word >= 0 && (one_word >> 2) == i) (&v.x)[one_word & 3] = 1u;
+        head[i] = v;
+    }
+}
+
 template <int NCH, int MR, int RBT, bool CONTRAST>
 static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST>);
@@ -1147,12 +1157,15 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, (unsigned)L.lds_bytes, &nb);
     if (err != hipSuccess) return err;
-    err = hipMemsetAsync(p.ws, 0, L.head_bytes, stream);
+    // The control block is zeroed by a kernel of ours, not by hipMemsetAsync: captured in a HIP graph next to other fill /
+    // memset nodes (a module step under torch.cuda.graph), the memset node replayed with another node's pattern from the
+    // second replay on -- the block came up as 0x43C00000 everywhere, every team saw "already aborted" and the fall-back
+    // redid each call (tools/graph_module_step.py).  (p.test_abort: diagnostics, the abort word raised in front of the launch.)
+    hipLaunchKernelGGL(team_zero_head, dim3((L.head_bytes / 16 + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<uint4*>(p.ws), (int)(L.head_bytes / 16),
+                       p.test_abort ? (int)(offsetof(TeamCtl, abort_) / 4) : -1);
+    err = hipGetLastError();
     if (err != hipSuccess) return err;
-    if (p.test_abort) {
-        err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&reinterpret_cast<TeamCtl*>(p.ws)->abort_), 1, 1, stream);
-        if (err != hipSuccess) return err;
-    }
     // Every workgroup must be resident (they wait for each other): grid <= resident capacity is what a cooperative
     // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
     // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
