@@ -355,14 +355,15 @@ def main():
             module_step()
         extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
         # the same step captured once in a HIP graph and replayed (graphed.GraphedLossStep): the host work of the eager
-        # module path -- Python, autograd dispatch, allocator -- leaves the loop, the device operations stay
+        # module path -- Python, autograd dispatch, allocator -- leaves the loop, the device operations stay.  Measured in
+        # a CHILD process: graph capture exercises runtime paths nothing else here does, and whatever happens to it must
+        # not take the bench line with it.
         try:
-            from speaker_embedding_ge2e_loss_amd.graphed import GraphedLossStep
-            gstep = GraphedLossStep(GE2ELoss(HParams(device=dev), variant=variant, impl=args.impl), (N, M, D))
-            gstep(E[0])
-            torch.cuda.synchronize()
-            extra["latency_module_graph_b1_us"] = float(np.median(time_launches(lambda: gstep(), 100))) * 1e3
-        except Exception as ex:   # capture unsupported by this torch / runtime
+            r = subprocess.run([sys.executable, "-m", "speaker_embedding_ge2e_loss_amd.graphed", str(N), str(M), str(D),
+                                variant, args.impl], capture_output=True, text=True, timeout=180,
+                               cwd=os.path.dirname(os.path.abspath(__file__)))
+            extra.update(json.loads(r.stdout.strip().splitlines()[-1]))
+        except Exception as ex:   # capture unsupported by this torch / runtime, or the child died
             extra["latency_module_graph_b1_us"] = None
             extra["latency_module_graph_note"] = str(ex)[:160]
 
