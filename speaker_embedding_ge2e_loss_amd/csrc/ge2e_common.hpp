@@ -61,6 +61,10 @@ struct Problem {
 #define GE2E_PROF_FLUSH(n)                                             \
     if (threadIdx.x == GE2E_PROF_TID && p.prof)                                    \
         for (int prof_i = 0; prof_i < n; ++prof_i) atomicAdd(p.prof + prof_i, prof_acc[prof_i]);
+#elif defined(GE2E_MARKS)   // ISA reading aid: phase boundaries as comments in the -save-temps assembly, no code
+#define GE2E_PROF_DECL(n)
+#define GE2E_PROF(i) asm volatile("; PHASEMARK " #i)
+#define GE2E_PROF_FLUSH(n)
 #else
 #define GE2E_PROF_DECL(n)
 #define GE2E_PROF(i)

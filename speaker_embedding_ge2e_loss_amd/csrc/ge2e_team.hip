@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 
     float4 rowv[MR];            // this wave's rows of the batch about to start
     float4 held[NTI][RBC];      // ra gE + c1 e-hat of rows 16 rb + l15, columns 16 dt + 4 q ..   (GE -> next iteration)
-    float4 kjp = zero4();       // speaker row KJP'_j, this lane's 4 columns                      (F -> next F)
+    float kjb = 0.f;            // speaker row KJP_j = kjb c-hat_j: its coefficient                (F2 -> next F1)
     h8 ga[NTI][2][2] = {};      // GE's centroid fragments: columns 16 dt + l15, slots 32 s2 + 8 q .. (k-group form; GC -> next GE)
     float4 cj_cur = zero4(), cj_prev = zero4();   // c-hat_j, this lane's 4 columns
     float rn_cur = 0.f, kap_cur = 0.f, rn_prev = 0.f, kap_prev = 0.f;
@@ -378,9 +378,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const bool dact = D == 256 || d4 < D;   /* 64 lanes x 4 columns: every lane has columns at D = 256 */ \
     (void)l15; (void)q; (void)d4; (void)dact
 
-#ifdef GE2E_X_PRIO
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // the younger wave of each SIMD
-#endif
     GE2E_PROF_DECL(20)
 #ifdef GE2E_PROF_A1     // finer view of A1 (tools/profile_phases.py prints slots 14..18)
 #define GE2E_PROF_SUB(i) GE2E_PROF(i)
@@ -520,9 +517,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                                                       fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
                         }
                         if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
-#ifndef GE2E_X_NOSB_GE
                         __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
-#endif
                     }
                 }
 #undef T2_GE_LOAD
@@ -599,9 +594,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                     const float sc = lane_get(rs_l, scatter_lane(i));
                     if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(rowv[i], sc));
                 }
-#ifndef GE2E_X_NOSB_A2
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
-#endif
             }
         }
         // The next batch's rows are requested as soon as this batch's have become images: a whole iteration ahead of their
@@ -630,70 +623,58 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             float cf[1] = {dot4(gsum, cj_prev)};
             wave_sum_to_sgpr<1>(cf);
             const float coefc = cf[0];
-            const float f = kap_prev * coefc, sc = rn_prev * inv_m;
+            const float sc = rn_prev * inv_m, fk = kjb - kap_prev * coefc * sc;   // KJ_j = sc gC_j + (kjb - kap (gC_j . c-hat_j) sc) c-hat_j
             if (dact && have_prev)
                 *reinterpret_cast<float4*>(KJ + wid * D + d4) =
-                    make_float4((gsum.x - f * cj_prev.x) * sc + kjp.x, (gsum.y - f * cj_prev.y) * sc + kjp.y,
-                                (gsum.z - f * cj_prev.z) * sc + kjp.z, (gsum.w - f * cj_prev.w) * sc + kjp.w);
+                    make_float4(fmaf(gsum.x, sc, fk * cj_prev.x), fmaf(gsum.y, sc, fk * cj_prev.y),
+                                fmaf(gsum.z, sc, fk * cj_prev.z), fmaf(gsum.w, sc, fk * cj_prev.w));
         }
         __syncthreads();                 // KJ rows; every wave's ET rows and row scalars of cur are written
         GE2E_PROF(5);
 
         // ===== dE_r of prev = held part + KJ_{speaker of r}: two or three speakers per 16-row block ================
-        // The sums are formed IN the held registers and stored from there: nothing writes those registers again before
-        // the next GE.  (A store's data registers must not be reused soon after it: with the memory pipe backed up a
-        // queued store reads its data late.)  All KJ reads first, then the sums and stores: written as one loop hipcc
-        // recycles ONE temporary and serialises ten LDS round trips per wave (2.8 k cycles for the older wave of a SIMD,
-        // 6 k for the younger).  Tried and dropped: the stores under GC's MFMAs -- the wave blocks at store issue and
-        // GC went from 6 k to 10 k cycles (-7 % overall).
+        // All KJ reads first, then the sums and stores: written as one loop hipcc recycles ONE temporary and serialises
+        // ten LDS round trips per wave.  The sums go to fresh registers: formed in place (held += KJ) under a two-trip
+        // loop, every trip carried the forty held registers through phi copies -- 60 v_mov_b64 per wave and batch.
+        // Metric shape (M and the row count are compile-time): the speaker of row 16 rb + 8 i + x, x = l15 & 7, is
+        // (16 rb + 8 i) / M + (x >= M - (16 rb + 8 i) % M): a compile-time KJ row plus one of three lane offsets (0 or one
+        // KJ row), so a read is a base register and an immediate.  Tried and dropped: the stores under GC's MFMAs -- the
+        // wave blocks at store issue and GC went from 6 k to 10 k cycles (-7 % overall).
 #define T2_DE_STORES()                                                                                                     \
     do {                                                                                                                   \
             GE2E_T2_LANE();                                                                                                \
+            const int x8_ = l15 & 7;                                                                                       \
+            const float* const kjc_ = KJ + min(NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 4 * q, D - 4);             \
+            const unsigned de0_ = (unsigned)((j0 * M + (NTI == 2 ? x8_ : l15)) * D + (NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 4 * q)) * 4u; \
 _Pragma("unroll")                                                                                                          \
             for (int i = 0; i < NTI; ++i) {                                                                                \
                 float4 kjv[RBC];                                                                                           \
 _Pragma("unroll")                                                                                                          \
                 for (int rb = 0; rb < RBC; ++rb)                                                                           \
                     if (CT_DE || rb < RBr) {                                                                               \
-                                                                                                                           \
-                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
-                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
-                        kjv[rb] = *reinterpret_cast<const float4*>(KJ + min((r * L.mul_m) >> 16, 7) * D + min(c, D - 4));  \
+                        if (MEX) {                                                                                         \
+                            const int b0 = 16 * rb + 8 * i;                                                                \
+                            kjv[rb] = *reinterpret_cast<const float4*>(kjc_ + (b0 / MR) * D + (x8_ >= MR - b0 % MR ? D : 0)); \
+                        } else {                                                                                           \
+                            const int r = NTI == 2 ? 16 * rb + 8 * i + x8_ : 16 * rb + l15;                                \
+                            const int c = NTI == 2 ? 0 : 16 * T2_DT(i);                                                    \
+                            kjv[rb] = *reinterpret_cast<const float4*>(kjc_ + min((r * L.mul_m) >> 16, 7) * D + min(c, D - 16)); \
+                        }                                                                                                  \
                     }                                                                                                      \
 _Pragma("unroll")                                                                                                          \
                 for (int rb = 0; rb < RBC; ++rb)                                                                           \
                     if (CT_DE || rb < RBr) {                                                                               \
-                        const int r = NTI == 2 ? 16 * rb + 8 * i + (l15 & 7) : 16 * rb + l15;                              \
-                        const int c = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 16 * T2_DT(i) + 4 * q;               \
-                        const bool ok = r < R_my && T2_DT(i) < NT;                                                         \
-                        held[i][rb].x += kjv[rb].x; held[i][rb].y += kjv[rb].y;                                            \
-                        held[i][rb].z += kjv[rb].z; held[i][rb].w += kjv[rb].w;                                            \
-                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? (unsigned)((j0 * M + r) * D + c) * 4u : OOB, held[i][rb]);      \
+                        const int rc = NTI == 2 ? 16 * rb + 8 * i : 16 * rb;      /* row and column part that is not in de0_ */ \
+                        const int cc = NTI == 2 ? 0 : 16 * T2_DT(i);                                                       \
+                        const bool ok = MEX || (rc + (NTI == 2 ? x8_ : l15) < R_my && T2_DT(i) < NT);                      \
+                        const float4 o = make_float4(held[i][rb].x + kjv[rb].x, held[i][rb].y + kjv[rb].y,                 \
+                                                     held[i][rb].z + kjv[rb].z, held[i][rb].w + kjv[rb].w);                \
+                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? de0_ + (unsigned)(rc * D + cc) * 4u : OOB, o);                  \
                     }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
             }                                                                                                              \
     } while (0)
-        // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
-        // stores wait to issue.  Tried and dropped: the stores under GC's MFMAs (GC 6 k -> 10 k cycles, -7 % overall);
-        // the younger wave of every SIMD running GC first and storing after it (its GC + stores take the same 11 k).
-        // dE(prev) and X(cur) are independent (the stores read KJ and the held registers, X reads the images and writes the
-        // X block): the two waves of a SIMD take them in OPPOSITE order -- waves 0-3 store while waves 4-7 contract, then
-        // the other way round -- so a wave blocked at store issue shares its SIMD with one that feeds the matrix pipe.
-#ifndef GE2E_X_NO_PP_DEX
-#pragma unroll 1
-        for (int st_ = 0; st_ < 2; ++st_) {
-        if ((st_ == 0) == (wid < 4)) {
-#endif
-        if (want_grad && have_prev) T2_DE_STORES();
-#ifndef GE2E_X_NO_PP_DEX
-        } else {
         // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
-        if (have_cur) {
-            GE2E_T2_LANE();
-            float* const XBk = khX ? XB1 : XB0;
-            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
-            h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
-            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
 #define T2_X_LOAD(T_)                                                                                     \
     do {                                                                                                  \
         const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
@@ -703,36 +684,53 @@ _Pragma("unroll")                                                               
 #define T2_X_STORE(RB_)                                                                       \
     *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
         make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
-            T2_X_LOAD(0);
-#pragma unroll
-            for (int rb = 0; rb < RBC; ++rb) {
-                if (CT_X || rb < RBr) {
-                    acc[rb & 1] = acc_zero4();
-#pragma unroll
-                    for (int s = 0; s < NCH; ++s) {
-                        const int t = rb * NCH + s;
-                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
-                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
-#ifndef GE2E_X_NOSB_X
-                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
-#endif
-                    }
-                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
-                    if (rb > 0) { T2_X_STORE(rb - 1); }
-                }
-            }
-            if (CT_X) { T2_X_STORE(RBT - 1); }
-            else {
-#pragma unroll
-                for (int rb = 0; rb < RBC; ++rb)
-                    if (rb == RBr - 1) { T2_X_STORE(rb); }
-            }
+#define T2_X_CONTRACT()                                                                                                    \
+    do {                                                                                                                   \
+            GE2E_T2_LANE();                                                                                                \
+            float* const XBk = khX ? XB1 : XB0;                                                                            \
+            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   /* et_off's f of rows 16 rb + l15 */ \
+            h8 fb[2][2];            /* [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs */ \
+            f32x4 acc[2] = {acc_zero4(), acc_zero4()};                                                                     \
+            T2_X_LOAD(0);                                                                                                  \
+_Pragma("unroll")                                                                                                          \
+            for (int rb = 0; rb < RBC; ++rb) {                                                                             \
+                if (CT_X || rb < RBr) {                                                                                    \
+                    acc[rb & 1] = acc_zero4();                                                                             \
+_Pragma("unroll")                                                                                                          \
+                    for (int s = 0; s < NCH; ++s) {                                                                        \
+                        const int t = rb * NCH + s;                                                                        \
+                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);                            \
+                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);                             \
+                        __builtin_amdgcn_sched_barrier(0);   /* fragments at most one K-step ahead (registers) */          \
+                    }                                                                                                      \
+                    /* lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now */ \
+                    if (rb > 0) { T2_X_STORE(rb - 1); }                                                                    \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (CT_X) { T2_X_STORE(RBT - 1); }                                                                             \
+            else {                                                                                                         \
+_Pragma("unroll")                                                                                                          \
+                for (int rb = 0; rb < RBC; ++rb)                                                                           \
+                    if (rb == RBr - 1) { T2_X_STORE(rb); }                                                                 \
+            }                                                                                                              \
+            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;                                                \
+    } while (0)
+        // The stores of a workgroup leave at ~14 B/clk, 6 k cycles for all eight waves, and a wave blocks while its
+        // stores wait to issue.  dE(prev) and X(cur) are independent (the stores read KJ and the held registers, X reads
+        // the images and writes the X block): the two waves of a SIMD take them in OPPOSITE order -- waves 0-3 store while
+        // waves 4-7 contract, then the other way round -- so a wave blocked at store issue shares its SIMD with one that
+        // feeds the matrix pipe.  Both orders are written out (a two-trip loop around one copy made phis of everything
+        // that is live across it).
+        if (wid < 4) {
+            if (want_grad && have_prev) T2_DE_STORES();
+            if (have_cur) T2_X_CONTRACT();
+        } else {
+            if (have_cur) T2_X_CONTRACT();
+            if (want_grad && have_prev) T2_DE_STORES();
+        }
+#undef T2_X_CONTRACT
 #undef T2_X_LOAD
 #undef T2_X_STORE
-            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
-        }
-        } }
-#endif
 #undef T2_DE_STORES
         GE2E_PROF(6);
         // ---- previous batch: scalars out ----------------------------------------------------------------------------
@@ -748,52 +746,6 @@ _Pragma("unroll")                                                               
         }
         if (!have_cur) break;
 
-#ifdef GE2E_X_NO_PP_DEX
-        // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
-        if (have_cur) {
-            GE2E_T2_LANE();
-            float* const XBk = khX ? XB1 : XB0;
-            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
-            h8 fb[2][2];            // [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs
-            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
-#define T2_X_LOAD(T_)                                                                                     \
-    do {                                                                                                  \
-        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
-        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
-        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
-    } while (0)
-#define T2_X_STORE(RB_)                                                                       \
-    *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
-        make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
-            T2_X_LOAD(0);
-#pragma unroll
-            for (int rb = 0; rb < RBC; ++rb) {
-                if (CT_X || rb < RBr) {
-                    acc[rb & 1] = acc_zero4();
-#pragma unroll
-                    for (int s = 0; s < NCH; ++s) {
-                        const int t = rb * NCH + s;
-                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) T2_X_LOAD(t + 1);
-                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
-#ifndef GE2E_X_NOSB_X
-                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
-#endif
-                    }
-                    // lane (r = l15, q) holds X[16 tX + 4 q + i][16 rb + l15]; the previous block's sums are final now
-                    if (rb > 0) { T2_X_STORE(rb - 1); }
-                }
-            }
-            if (CT_X) { T2_X_STORE(RBT - 1); }
-            else {
-#pragma unroll
-                for (int rb = 0; rb < RBC; ++rb)
-                    if (rb == RBr - 1) { T2_X_STORE(rb); }
-            }
-#undef T2_X_LOAD
-#undef T2_X_STORE
-            if (tid < NC) *reinterpret_cast<float4*>(CST + tid * 4) = cstv;
-        }
-#endif
         GE2E_PROF(11);
         __syncthreads();
         GE2E_PROF(3);
@@ -804,7 +756,7 @@ _Pragma("unroll")                                                               
         // Lane (rr = lane >> 2, qq = lane & 3) holds the slots (sb + j) & 63, j = 0..15, sb = (own slot & ~3) + 16 qq:
         // aligned groups of four, and the own-speaker column is always one of values 0..3 of the lane qq == 0.
         float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
-        float c3v = 0.f, c4v = 0.f;     // row coefficients c3', c4' of row i in lane 4 i (S -> F2, same wave: no LDS trip)
+        float c4v = 0.f;                // row coefficient c4' of row i in lane 4 i (S -> F2, same wave: no LDS trip)
         if (have_cur && want_grad && R_my < RT) {   // image rows without a speaker: the KJ rows of F1 have been lying there
             for (int i = tid; i < (RT - R_my) * GP / 8; i += 512) {
                 reinterpret_cast<float4*>(Gh + R_my * GP)[i] = zero4();
@@ -937,12 +889,13 @@ _Pragma("unroll")                                                               
                 const float alpha = ad * rnu * (1.0f + t1 * ne);
                 const float beta = -ad * rnu * t1;
                 const float o = c2_0 * cs.z * ne;
-                // o also lands in this member's partial gC of slot ko (W = w sum_i o_i e-hat_i); KJ_j is linear in gC,
-                // so W is taken out through the speaker row: c3' = c3 - (rn_j / M) w o, c4' += (rn_j / M) kap_j w o xo
-                const float lam = cs.x * inv_m * w;
-                const float c3p = (alpha * inv_m1 - lam * o) * kSplitInv;           // c3'
-                const float c4p = beta * inv_m1 * cs.z + lam * cs.y * o * xo;       // c4' (of c-hat_j)
-                c3v = rv && own_lane ? c3p : 0.f;
+                // o also lands in this member's partial gC of slot ko: W = w sum_i o_i e-hat_i.  KJ_j is linear in gC, and
+                // pushed through the centroid norm W is EXACTLY the leave-one-out speaker row sum_i c3_i e-hat_i
+                // (c3 = alpha / (M - 1); (rn_j / M) w o = c3 because rn_j |s_j| / M = 1 and rne |e| = 1) minus
+                // kap_j (sum_i c3_i xo_i) c-hat_j.  So the e-hat part of KJP_j is already in gC and only a multiple of
+                // c-hat_j is left: c4' = c4 + kap_j c3 xo.  (Rounds 2-3 formed c3' = c3 - (rn_j / M) w o -- rounding
+                // noise around zero -- and spent 190 instructions per wave and batch on sum_i c3'_i e-hat_i.)
+                const float c4p = inv_m1 * (beta * cs.z + cs.y * alpha * xo);       // c4' (of c-hat_j)
                 c4v = rv && own_lane ? c4p : 0.f;
                 if (rv && own_lane)
                     *reinterpret_cast<float2*>(RS + r * 8 + 4) =
@@ -970,11 +923,6 @@ _Pragma("unroll")                                                               
 
         // F2 (vector work on the images) and GC (matrix pipe, stores) are independent: opposite order on the two waves of
         // a SIMD, as for dE / X above
-#ifdef GE2E_X_PP_FGC
-#pragma unroll 1
-        for (int st2_ = 0; st2_ < 2; ++st2_) {
-        if ((st2_ == 0) == (wid < 4)) {
-#endif
         // GE's centroid fragments (k-group form, published in this iteration's A1) are requested HERE, in front of the two
         // phases that issue no memory instruction (F2 is vector work, GC's contraction reads LDS): the address path is
         // idle now and saturated behind GC's contraction, where these eight 1-KB loads per wave used to stand in front of
@@ -991,9 +939,7 @@ _Pragma("unroll")                                                               
             }                                                                                                             \
         }                                                                                                                 \
     } while (0)
-#ifndef GE2E_X_GA_LATE
         if (want_grad) { GE2E_T2_LANE(); T2_GA_LOAD(); }
-#endif
         // ===== F2: member scalars out; KJP'_j of cur (wave-local: it stays in registers until the next F1) ==========
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
@@ -1001,39 +947,12 @@ _Pragma("unroll")                                                               
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
             bstore4(rsX, XO.sc[buf] + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
-        if (want_grad && has_spk) {
-            GE2E_T2_LANE();
-            // speaker row KJP'_j = sum_i c3'_i e-hat_i + (sum_i c4'_i) c-hat_j (this lane's 4 columns)
-            kjp = zero4();
+        if (want_grad && has_spk) {   // speaker row KJP_j = (sum_i c4'_i) c-hat_j: one scalar, kept for the next F1
             float bs[1] = {c4v};
             wave_sum_to_sgpr<1>(bs);
-            const float bsum = bs[0];
-            // all image reads first (two 8-byte reads a row), then the sums: written as one loop hipcc recycles one pair of
-            // registers and serialises the LDS round trips
-            h4 eh[MR], el[MR];
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                const int off = et_off<D>(rbase + min(i, M - 1), min(d4, D - 4));
-                eh[i] = *reinterpret_cast<const h4*>(ETh + off);
-                el[i] = *reinterpret_cast<const h4*>(ETl + off);
-            }
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                if (i < M) {
-                    const float c3 = lane_get(c3v, 4 * i);
-                    kjp.x = fmaf((float)eh[i][0], c3, fmaf((float)el[i][0], c3, kjp.x));
-                    kjp.y = fmaf((float)eh[i][1], c3, fmaf((float)el[i][1], c3, kjp.y));
-                    kjp.z = fmaf((float)eh[i][2], c3, fmaf((float)el[i][2], c3, kjp.z));
-                    kjp.w = fmaf((float)eh[i][3], c3, fmaf((float)el[i][3], c3, kjp.w));
-                }
-            }
-            kjp.x += bsum * cj_cur.x; kjp.y += bsum * cj_cur.y; kjp.z += bsum * cj_cur.z; kjp.w += bsum * cj_cur.w;
-            if (!dact) kjp = zero4();
+            kjb = bs[0];
         }
         GE2E_PROF(12);
-#ifdef GE2E_X_PP_FGC
-        } else {
-#endif
         if (want_grad) {
             // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
             // dead (requested before it they cost 32 more registers under the accumulators and the allocator spilled
@@ -1049,13 +968,23 @@ _Pragma("unroll")                                                               
 #pragma unroll
                         for (int i = 0; i < 16; ++i) gc[b][i] = 0.f;
                     h8 gf[2][2], ef[2][2][2];     // [set][hi, lo], [set][b][hi, lo]
+                    // Both swizzles are periodic in 16 rows (g_off: 8), so a K-step's fragment addresses are the K-step-0
+                    // addresses plus a compile-time row offset: six lane offsets per phase and immediates after that.  (Written
+                    // with the K-step inside g_off / et_off, hipcc re-derived every swizzle per step: 190 integer instructions
+                    // per wave and batch in this phase alone.)
+                    const int r0_ = 8 * (lv_ >> 5) + ((lv_ & 15) >> 2), c0_ = 16 * ((lv_ >> 4) & 1) + 4 * (lv_ & 3);
+                    const int gA = g_off(r0_, 32 * kh + c0_), gB = g_off(r0_ + 4, 32 * kh + c0_);
+                    const int eA[2] = {et_off<D>(r0_, 64 * sl + c0_), et_off<D>(r0_, 64 * sl + 32 + c0_)};
+                    const int eB[2] = {et_off<D>(r0_ + 4, 64 * sl + c0_), et_off<D>(r0_ + 4, 64 * sl + 32 + c0_)};
+#define T2_TR8(IMG_, A_, B_, ROWS_) \
+    __builtin_shufflevector(tr_read4((IMG_) + (A_) + (ROWS_)), tr_read4((IMG_) + (B_) + (ROWS_)), 0, 1, 2, 3, 4, 5, 6, 7)
 #define T2_GC_LOAD(S_)                                                                   \
     do {                                                                                 \
-        gf[(S_) & 1][0] = frag_tr_g(Gh, 16 * (S_), 32 * kh, lv_);                        \
-        gf[(S_) & 1][1] = frag_tr_g(Gl, 16 * (S_), 32 * kh, lv_);                        \
+        gf[(S_) & 1][0] = T2_TR8(Gh, gA, gB, 16 * (S_) * GP);                            \
+        gf[(S_) & 1][1] = T2_TR8(Gl, gA, gB, 16 * (S_) * GP);                            \
         _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                  \
-            ef[(S_) & 1][b][0] = frag_tr_et<D>(ETh, 16 * (S_), 64 * sl + 32 * b, lv_);     \
-            ef[(S_) & 1][b][1] = frag_tr_et<D>(ETl, 16 * (S_), 64 * sl + 32 * b, lv_);     \
+            ef[(S_) & 1][b][0] = T2_TR8(ETh, eA[b], eB[b], 16 * (S_) * P);               \
+            ef[(S_) & 1][b][1] = T2_TR8(ETl, eA[b], eB[b], 16 * (S_) * P);               \
         }                                                                                \
     } while (0)
                     T2_GC_LOAD(0);
@@ -1065,15 +994,11 @@ _Pragma("unroll")                                                               
                             if (s + 1 < RBC && (CT_GC || s + 1 < RBr)) T2_GC_LOAD(s + 1);
 #pragma unroll
                             for (int b = 0; b < 2; ++b) mfma32x3(gc[b], gf[s & 1][0], gf[s & 1][1], ef[s & 1][b][0], ef[s & 1][b][1]);
-#ifndef GE2E_X_NOSB_GC
                             __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
-#endif
                         }
                     }
 #undef T2_GC_LOAD
-#ifdef GE2E_X_GA_LATE
-                    T2_GA_LOAD();
-#endif
+#undef T2_TR8
                     // the single partial-gradient buffer: the previous batch's partials must have been read by everybody
                     bool ok = true;
                     if (seq > 0) {
@@ -1119,17 +1044,11 @@ _Pragma("unroll")                                                               
                         }
                     }
                 } else {
-#ifdef GE2E_X_GA_LATE
-                    T2_GA_LOAD();
-#endif
                 }
             }
 #undef T2_GA_LOAD
             GE2E_PROF(7);
         }
-#ifdef GE2E_X_PP_FGC
-        } }
-#endif
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     GE2E_PROF_FLUSH(20)
