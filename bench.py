@@ -131,7 +131,8 @@ def verify_launch(E, out, N, M, D, variant, w=10.0, b=-5.0):
     middle) against the fp64 closed-form oracle.  The oracle is the checker here, never the thing timed."""
     from oracle import ge2e_oracle as orc
     B = E.shape[0]
-    picks = sorted({i for i in (0, 31, 32, B // 2 - 1, B // 2, B - 1) if 0 <= i < B})
+    cand = (0, 31, 32, B // 2 - 1, B // 2, B - 1) if N * N * M * D <= 64 * 64 * 10 * 256 * 64 else (0, B // 2, B - 1)
+    picks = sorted({i for i in cand if 0 <= i < B})   # the fp64 closed form of one N=1024, D=768 batch takes seconds
     worst = {"max_loss_rel": 0.0, "max_dE_relfro": 0.0, "max_dw_rel": 0.0, "max_db_abs": 0.0}
     for i in picks:
         ref = orc.closed_form(E[i].cpu().numpy(), w, b, variant=variant)
@@ -144,6 +145,21 @@ def verify_launch(E, out, N, M, D, variant, w=10.0, b=-5.0):
     ok = (worst["max_loss_rel"] <= 1e-4 and worst["max_dE_relfro"] <= 1e-4 and worst["max_dw_rel"] <= 1e-4
           and worst["max_db_abs"] <= 1e-4 and all(np.isfinite(v) for v in worst.values()))
     return {"batches": picks, **worst, "tolerance": "loss rtol 1e-4, dE rel-Frobenius 1e-4, dw rtol 1e-4, db atol 1e-4",
+            "oracle": "oracle.ge2e_oracle.closed_form (fp64)", "ok": bool(ok)}
+
+
+def verify_forward(E, loss, per, N, M, D, variant, w=10.0, b=-5.0):
+    """The forward-only launch (dE = NULL): loss and per-row losses of sampled batches against the fp64 oracle."""
+    from oracle import ge2e_oracle as orc
+    B = E.shape[0]
+    picks = sorted({i for i in (0, 31, 32, B // 2, B - 1) if 0 <= i < B})
+    worst = {"max_loss_rel": 0.0, "max_per_abs": 0.0}
+    for i in picks:
+        ref = orc.closed_form(E[i].cpu().numpy(), w, b, variant=variant, want_grad=False)
+        worst["max_loss_rel"] = max(worst["max_loss_rel"], abs(float(loss[i]) - ref["loss"]) / max(abs(ref["loss"]), 1e-30))
+        worst["max_per_abs"] = max(worst["max_per_abs"], float(np.abs(per[i].cpu().numpy().astype(np.float64) - ref["per"]).max()))
+    ok = worst["max_loss_rel"] <= 1e-4 and worst["max_per_abs"] <= 1e-3 and all(np.isfinite(v) for v in worst.values())
+    return {"batches": picks, **worst, "tolerance": "loss rtol 1e-4, per-row loss atol 1e-3",
             "oracle": "oracle.ge2e_oracle.closed_form (fp64)", "ok": bool(ok)}
 
 
@@ -191,6 +207,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the B=1 latency legs and the exact-fp32 comparison (profiling runs: only the benched kernel)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle check of sampled batches")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="profiling runs: the timed step is the forward-only launch (dE = NULL: similarity + loss, the "
+                         "workload of s4:61-110 / s5:42-44); the JSON line then carries only the forward_only object's numbers")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: ranks, rendezvous (gloo), the bucket all-reduce and the JSON line only; value is null")
     args = ap.parse_args()
@@ -248,6 +267,15 @@ def main():
         def step():
             GF.loss_fwd_bwd(E, w, b, variant=variant, impl=impl, out=out, workspace=ws)
 
+        # similarity + loss only (dE = NULL): what the reference's evaluation paths run (s4:61-110 test loss, s5:42-44)
+        out_f = GF.LossOutputs(loss=torch.empty(B, device=dev), per=torch.empty(B, N, M, device=dev), dE=None, dw=None, db=None)
+
+        def step_fwd():
+            GF.loss_fwd_bwd(E, w, b, variant=variant, impl=impl, need_grad=False, out=out_f, workspace=ws)
+
+        if args.forward_only:
+            step = step_fwd
+
     bucket = None
     if args.mode == "train-step":
         bucket = torch.zeros(BUCKET_FLOATS, device=dev)
@@ -294,13 +322,25 @@ def main():
 
     tmax = elapsed
     loss_mean = None
+    rccl_ranks, per_rank_s = 1, [elapsed]
     if dist and world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
+        # what the collective library itself saw: a one-element SUM of ones over the job's backend (nccl = RCCL on the
+        # GPU box, gloo in a dry run) must come back as the number of ranks, and every rank's own clock is gathered
+        one = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(one.item())))
+        if rccl_ranks != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: the process group answers {rccl_ranks} ranks (world size {dist.get_world_size()}), launched {world}")
+        gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        per_rank_s = [float(g.item()) for g in gathered]
     if not dry:
         # the only cross-rank reduction of the loss-only job: loss / dw / db sums
-        red = torch.stack([out.loss.sum(), out.dw.sum(), out.db.sum()])
+        red = (torch.stack([out_f.loss.sum()] * 3) if args.forward_only
+               else torch.stack([out.loss.sum(), out.dw.sum(), out.db.sum()]))
         if dist and world > 1:
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
         loss_mean = float(red[0].item()) / (B * world)
@@ -328,7 +368,26 @@ def main():
                  "allreduce_busbw_GBs": (2 * (world - 1) / world * nbytes / (el_ar / args.steps) / 1e9) if world > 1 else None}
 
     extra = {}
-    if rank == 0 and not dry and args.mode == "loss" and not args.no_extras:
+    if rank == 0 and not dry and args.mode == "loss" and not args.no_extras and not args.forward_only:
+        # similarity + loss only (dE = NULL): north_star's "GE2E similarity+loss" sentence and the reference's evaluation
+        # paths.  Algorithmic bytes = N M D 4 per batch (E read once, nothing of that size written), flops = 2 N^2 M D.
+        for _ in range(3):
+            step_fwd()
+        torch.cuda.synchronize()
+        msf = float(np.mean(time_launches(step_fwd, max(5, min(20, args.steps)))))
+        fb, ff = N * M * D * 4, 2 * N * N * M * D
+        gbs = fb * B / (msf * 1e-3) / 1e9
+        itf = ff * B / (msf * 1e-3) / 1e12 * (3 if impl in SPLIT_IMPLS else 1)
+        fwd_mfma = impl in SPLIT_IMPLS and itf / MFMA_F16_PEAK_TF > gbs / HBM_PEAK_GBS
+        extra["forward_only"] = {
+            "workload": f"{args.config}: similarity + loss only (dE = NULL), B={B} batches per launch, impl {impl}",
+            "value": B / (msf * 1e-3), "unit": "batches/s", "ms_per_launch": msf,
+            "roofline": ({"bound": "mfma", "achieved": itf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": itf / MFMA_F16_PEAK_TF}
+                         if fwd_mfma else
+                         {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}),
+            "algorithmic_bytes_per_launch": fb * B, "algorithmic_flops_per_launch": ff * B,
+            "verify": None if args.no_verify else verify_forward(E, out_f.loss, out_f.per, N, M, D, variant)}
+    if rank == 0 and not dry and args.mode == "loss" and not args.no_extras and not args.forward_only:
         # B = 1 latency, raw C-ABI call (not the metric; launch-bound single batches)
         e1 = E[:1].contiguous()
         o1 = GF.LossOutputs(loss=out.loss[:1], per=None, dE=out.dE[:1], dw=out.dw[:1], db=out.db[:1])
@@ -424,16 +483,19 @@ def main():
         extra["encoder_tail"] = tails
 
     verify = None
-    if rank == 0 and not dry and args.mode == "loss" and not args.no_verify and N * N * M * D <= 64 * 64 * 10 * 256 * 64:
+    if rank == 0 and not dry and args.mode == "loss" and not args.no_verify:
         step()   # the benched implementation's outputs (the exact-fp32 leg may have run since)
         torch.cuda.synchronize()
-        verify = verify_launch(E, out, N, M, D, variant)
+        verify = (verify_forward(E, out_f.loss, out_f.per, N, M, D, variant) if args.forward_only
+                  else verify_launch(E, out, N, M, D, variant))
 
     if rank == 0:
         total_batches = B * args.steps * world
         value = None if dry else total_batches / tmax
         bytes_per_batch = 2 * N * M * D * 4  # read E once + write dE once
         flops_per_batch = 6 * N * N * M * D  # three N x (N M) x D contractions, 2 flops per MAC
+        if args.forward_only:                # E read once, one contraction
+            bytes_per_batch, flops_per_batch = N * M * D * 4, 2 * N * N * M * D
         split = impl in SPLIT_IMPLS
         roof = None
         if not dry:
@@ -464,13 +526,15 @@ def main():
                         "frac": alg_gbs / HBM_PEAK_GBS, "traffic": (tp or {}).get("bytes"), "traffic_from_profile": tp, **common}
         name = {"loss": "GE2E loss+backward throughput", "train-step": "GE2E data-parallel train-step throughput "
                 "(loss+backward + flat-bucket grad all-reduce)"}[args.mode]
+        if args.forward_only:
+            name = "GE2E similarity+loss (forward-only, dE = NULL) throughput"
         line = {
             "metric": f"{name}, (spk x utt) batches/sec at N={N} M={M} D={D}",
             "value": value, "unit": "batches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "arith": ARITH[impl in SPLIT_IMPLS] if not dry else None,
             "data": "synthetic" if not dry else "dry-run (no kernel launched)",
-            "config": {"workload": f"{args.config}: N={N} M={M} D={D} {variant} GE2E fwd+bwd, "
+            "config": {"workload": f"{args.config}: N={N} M={M} D={D} {variant} GE2E " + ("forward only, " if args.forward_only else "fwd+bwd, ") +
                                    f"B={B} batches per launch per GPU, w=10 b=-5"
                                    + (f", + SUM all-reduce of {BUCKET_FLOATS} fp32 grads per step" if train else ""),
                        "mode": args.mode, "N": N, "M": M, "D": D, "variant": variant, "batches_per_launch": B,
@@ -479,6 +543,10 @@ def main():
                                       (", one flat-bucket all-reduce per step)" if train else ", no data-path collective)")},
             "roofline": roof,
             "loss_mean": loss_mean,
+            # ranks the collective backend counted (a real 1-element all-reduce; 1 = single process, no group) and each
+            # rank's own rate over its own clock: value uses the slowest rank's time
+            "rccl_ranks": rccl_ranks,
+            "per_rank_value": [None if dry else B * args.steps / t_ for t_ in per_rank_s],
         }
         if variant == "contrast":
             line["parity"] = ("unpinned: the reference has no contrast variant (s3 implements softmax only); checked "
@@ -500,10 +568,9 @@ def main():
         dist = None
     if verify is not None and not verify["ok"]:
         raise SystemExit("bench.py: the benched launch does not match the oracle: " + json.dumps(verify))
-    if dist:
-        if world > 1:
-            dist.barrier()
-        dist.destroy_process_group()
+    fo = extra.get("forward_only")
+    if fo and fo.get("verify") and not fo["verify"]["ok"]:
+        raise SystemExit("bench.py: the forward-only launch does not match the oracle: " + json.dumps(fo["verify"]))
 
 
 if __name__ == "__main__":

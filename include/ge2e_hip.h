@@ -58,9 +58,7 @@ extern "C" {
 #define GE2E_IMPL_AUTO_NO_TEAM 7 /* AUTO without GE2E_IMPL_TEAM: for callers that KNOW other streams or processes keep
                                    CUs busy while the loss runs (overlapped collectives, a shared GPU).  The team kernel
                                    wants its workgroups co-resident; it survives a busy device (waits bounded to a few
-                                   milliseconds, then the fall-back launch), but not choosing it saves those waits.  The
-                                   environment variable GE2E_AUTO_NO_TEAM=1 (read once per process) turns every AUTO
-                                   into this. */
+                                   milliseconds, then the fall-back launch), but not choosing it saves those waits.  */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */

@@ -34,14 +34,8 @@ constexpr int kSplitMinB = 208, kSplitMaxB = 256;
 
 // The team kernel wants its workgroups co-resident.  It survives a busy device (waits bounded to milliseconds, then the
 // gated fall-back launch redoes the call), but a caller that KNOWS it shares the GPU -- overlapped collectives, several
-// processes -- asks for GE2E_IMPL_AUTO_NO_TEAM; GE2E_AUTO_NO_TEAM=1 in the environment (read once) does it for every AUTO.
-bool auto_may_team() {
-    static const int allowed = [] {
-        const char* e = getenv("GE2E_AUTO_NO_TEAM");
-        return (e && e[0] && e[0] != '0') ? 0 : 1;
-    }();
-    return allowed != 0;
-}
+// processes -- asks for GE2E_IMPL_AUTO_NO_TEAM (the only switch: the GE2E_AUTO_NO_TEAM environment override of rounds 2-3
+// is gone, an implementation choice is an argument of the call).
 
 int resolve(int B, int N, int M, int D, int variant, int impl) {
     (void)variant;
@@ -51,7 +45,7 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
             // a few dozen rows: one wave per batch, exact fp32 (31..64 rows: from a few hundred batches per launch on --
             // 117-277 us against 262-408 us at B = 4096, but 30-44 us against 20-28 us for a single batch)
             if (wave_supports(N, M, D) && (!wave_is_large(N, M) || B >= 384)) return GE2E_IMPL_WAVE;
-            if (impl == GE2E_IMPL_AUTO && !(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D) && auto_may_team()) return GE2E_IMPL_TEAM;
+            if (impl == GE2E_IMPL_AUTO && !(B >= kSplitMinB && B <= kSplitMaxB) && N >= 16 && team_supports(N, M, D)) return GE2E_IMPL_TEAM;
             if (fused_split_supports(N, M, D)) return GE2E_IMPL_FUSED_SPLIT;
             return tiled_supports(N, M, D) ? GE2E_IMPL_TILED : GE2E_IMPL_GENERIC;
         case GE2E_IMPL_GENERIC: return GE2E_IMPL_GENERIC;

@@ -1,5 +1,6 @@
 // Shared device helpers for the GE2E HIP kernels (gfx950 / wave64 only).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -306,24 +307,44 @@ inline int device_cu_count() {
     }
     return 256;
 }
-// Per-(device, kernel) launch state of a kernel with dynamic LDS: the opt-in attribute is set and the occupancy asked
-// once per device for the largest LDS request seen, not on every call (two HIP API calls per launch otherwise).
+// Per-(device, kernel) launch state of a kernel with dynamic LDS (two HIP API calls per launch otherwise).  Host threads may
+// launch the same instantiation with different LDS sizes at once, so the state is guarded by a mutex and:
+//  * the opt-in attribute (MaxDynamicSharedMemorySize) is only ever RAISED -- lowering it between another thread's
+//    prepare_kernel and its launch would fail that launch;
+//  * the occupancy is remembered per (device, LDS size) in a small table, never paired with another size's answer (the
+//    team launch's co-residency check, grid <= blocks x CUs, depends on it).
 struct KernelLaunchState {
-    unsigned lds[kMaxDevices] = {};   // bytes the attribute has been raised to
-    int blocks[kMaxDevices] = {};     // hipOccupancyMaxActiveBlocksPerMultiprocessor at that size
+    static constexpr int kSizes = 4;
+    std::mutex mu;
+    unsigned attr[kMaxDevices] = {};              // bytes the attribute has been raised to on this device
+    unsigned lds[kMaxDevices][kSizes] = {};       // LDS sizes asked about ...
+    int blocks[kMaxDevices][kSizes] = {};         // ... and hipOccupancyMaxActiveBlocksPerMultiprocessor at each
+    int next[kMaxDevices] = {};                   // round-robin replacement
 };
 inline hipError_t prepare_kernel(KernelLaunchState& st, const void* fn, int threads, unsigned lds_bytes, int* blocks_per_cu) {
     const int dev = current_device_slot();
-    if (dev >= 0 && st.lds[dev] == lds_bytes && st.blocks[dev] > 0) {
-        if (blocks_per_cu) *blocks_per_cu = st.blocks[dev];
-        return hipSuccess;
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (dev >= 0 && st.attr[dev] >= lds_bytes)
+        for (int i = 0; i < KernelLaunchState::kSizes; ++i)
+            if (st.lds[dev][i] == lds_bytes && st.blocks[dev][i] > 0) {
+                if (blocks_per_cu) *blocks_per_cu = st.blocks[dev][i];
+                return hipSuccess;
+            }
+    hipError_t err;
+    if (dev < 0 || st.attr[dev] < lds_bytes) {
+        err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return err;
+        if (dev >= 0) st.attr[dev] = lds_bytes;
     }
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (err != hipSuccess) return err;
     int nb = 0;
     err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds_bytes);
     if (err != hipSuccess) return err;
-    if (dev >= 0 && nb > 0) { st.lds[dev] = lds_bytes; st.blocks[dev] = nb; }
+    if (dev >= 0 && nb > 0) {
+        const int i = st.next[dev];
+        st.next[dev] = (i + 1) % KernelLaunchState::kSizes;
+        st.lds[dev][i] = lds_bytes;
+        st.blocks[dev][i] = nb;
+    }
     if (blocks_per_cu) *blocks_per_cu = nb;
     return hipSuccess;
 }

@@ -29,7 +29,8 @@ constexpr int MAX_XCD = 8;
 constexpr unsigned long long TEAM_FORM_TICKS = 200000ull;      // 2 ms: every workgroup of the grid has started
 constexpr unsigned long long TEAM_HANDOFF_TICKS = 400000ull;   // 4 ms: a hand-off inside a running team
 
-// Control block at the head of the workspace; zeroed by a memset node in front of every launch.
+// Control block at the head of the workspace; zeroed by the team_zero_head kernel in front of every launch (not a memset
+// node: captured in a HIP graph beside torch's fill nodes, a memset node replayed with another node's pattern).
 // Each word that is polled or bumped sits on its own 128-byte line.
 struct TeamCtl {
     unsigned arrived;   unsigned pad0[31];

@@ -6,7 +6,7 @@
 
 namespace ge2e {
 
-// per-team counters, each on a 128-byte line of its own; zeroed by the memset node in front of the launch
+// per-team counters, each on a 128-byte line of its own; zeroed by the team_zero_head kernel in front of the launch
 struct TeamKFlags {
     unsigned c1;   unsigned pad0[31];   // hand-off 1: unit centroids of a batch published   (+1 per member)
     unsigned c2;   unsigned pad1[31];   // hand-off 2: partial centroid gradients published  (+1 per member)

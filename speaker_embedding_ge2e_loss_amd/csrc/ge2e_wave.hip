@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
         const float* Eb = p.E + (size_t)bi * NM * D + 4 * lane;
         float4 e[NX * M];
         int srow = 0;         // RAW: lane r = the row of Y that is row r of the (N,M,D) block
+        int sok = 1;          // RAW: ... and whether src named a row inside the batch (a caller's unvalidated index tensor:
+                              // an entry outside range(N M) reads a clamped row and its dY store is dropped)
         float rny = 0.f;      // RAW: lane r = 1 / |y_r|
         if (!RAW) {
 #pragma unroll
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
                     e[j * M + i] = (act && j < N) ? *reinterpret_cast<const float4*>(Eb + (size_t)(j * M + i) * D) : z4;
         } else {
             srow = rowv ? (p.src ? p.src[(size_t)bi * NM + lane] : lane) : 0;
+            sok = (unsigned)srow < (unsigned)NM;
+            srow = min(max(srow, 0), NM - 1);
 #pragma unroll
             for (int j = 0; j < NX; ++j)
 #pragma unroll
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, (4 * NX * M + 16 * NX > 200 ? 1 : 2)) void ge2
                             const int r = j * M + i;
                             const int sr = __builtin_amdgcn_readlane(srow, r);
                             const float rn = lane_get(rny, r), t = eg[i];
-                            if (act)
+                            if (act && __builtin_amdgcn_readlane(sok, r))
                                 *reinterpret_cast<float4*>(Gb + (size_t)sr * D) =
                                     make_float4((e[r].x - t * yh[i].x) * rn, (e[r].y - t * yh[i].y) * rn,
                                                 (e[r].z - t * yh[i].z) * rn, (e[r].w - t * yh[i].w) * rn);

@@ -46,3 +46,15 @@ class SpeakerEncoder(nn.Module):
         if not self.normalize:
             return y
         return y / torch.norm(y, dim=1).unsqueeze(1)  # s2:34
+
+
+def get_pre_trained_embedding_model(hp, use_path_as_absolute: bool = False) -> SpeakerEncoder:
+    """The reference's loader of the same name (s2:38-67): a fresh encoder built from ``hp``, the encoder-only checkpoint
+    ``hp.m_ge2e.best_model_path`` (joined with ``hp.general.project_root`` unless ``use_path_as_absolute``) loaded into
+    it, eval mode, on ``hp.general.device``.  The file format is the reference's (s4:130: the module's ``state_dict``),
+    which is also what ``DPTrainer.save_checkpoint`` writes."""
+    import os
+    model = SpeakerEncoder.from_hp(hp)
+    path = hp.m_ge2e.best_model_path if use_path_as_absolute else os.path.join(hp.general.project_root, hp.m_ge2e.best_model_path)
+    model.load_state_dict(torch.load(path, map_location=hp.general.device))
+    return model.eval().to(hp.general.device)

@@ -77,18 +77,33 @@ class _on_device:
 # Per-(shape, device) workspace sizes and per-(device, stream) workspace tensors of the module path.  The size depends on
 # the device (its CU count), so the query runs with that device current.  A workspace is reused only by launches on the
 # SAME stream, which the stream itself serialises; callers that pass `workspace=` are unaffected.
+#  * While the current stream is being CAPTURED the cache is neither read nor written: the workspace comes from the
+#    allocator, i.e. from the capturing graph's private pool, which lives as long as the graph.  (A cached pointer baked
+#    into a graph would dangle as soon as a later, larger eager call on that stream replaced the cache entry, and two
+#    graphs captured on torch's one capture stream would share -- and race on -- one workspace.)
+#  * The cache holds at most _WS_CACHE_MAX (device, stream) entries, least recently used out first: a process that keeps
+#    creating streams does not keep a workspace (with a large launch's fall-back slices) per dead stream forever.  A
+#    dropped or outgrown workspace goes back to the caching allocator, which hands a block out again only in the order
+#    of the stream it was allocated on -- the launches still using it are ahead in that very stream.
 _ws_bytes_cache: dict = {}
 _ws_cache: dict = {}
+_WS_CACHE_MAX = 8
+_capturing = getattr(torch.cuda, "is_current_stream_capturing", None)
 
 
 def _workspace_for(lib, dev: torch.device, stream: int, key: tuple) -> torch.Tensor:
     need = _ws_bytes_cache.get(key)
     if need is None:
         need = _ws_bytes_cache[key] = int(lib.ge2e_workspace_bytes(*key[:6]))
+    if _capturing is not None and _capturing():
+        return alloc_workspace(need, dev)
     k = (key[6], stream)
-    ws = _ws_cache.get(k)
+    ws = _ws_cache.pop(k, None)                 # re-inserted below: dict order = recency
     if ws is None or ws.numel() < need:
-        ws = _ws_cache[k] = alloc_workspace(need, dev)
+        ws = alloc_workspace(need, dev)
+        while len(_ws_cache) >= _WS_CACHE_MAX:
+            _ws_cache.pop(next(iter(_ws_cache)))
+    _ws_cache[k] = ws
     return ws
 
 
@@ -105,6 +120,16 @@ def resolve_impl(B: int, N: int, M: int, D: int, variant: str = "softmax", impl:
 def alloc_workspace(nbytes: int, device) -> torch.Tensor:
     # torch's caching allocator returns >= 512-byte aligned blocks; the library wants 256
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _check_scalar_params(w: torch.Tensor, b: torch.Tensor, dev: torch.device):
+    """w and b cross the C ABI as raw device pointers to one fp32 each: anything else would be a wild device read."""
+    for name, t in (("w", w), ("b", b)):
+        _require_cuda(t, name)
+        if t.dtype != torch.float32 or t.numel() != 1:
+            raise TypeError(f"{name} must be a float32 scalar tensor")
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, embeddings on {dev}: raw pointers cross the C ABI, all on one device")
 
 
 @dataclass
@@ -131,12 +156,7 @@ def loss_fwd_bwd(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *,
     e4, _ = _as_batched(embeddings)
     B, N, M, D = e4.shape
     dev = e4.device
-    for name, t in (("w", w), ("b", b)):
-        _require_cuda(t, name)
-        if t.dtype != torch.float32 or t.numel() != 1:
-            raise TypeError(f"{name} must be a float32 scalar tensor")
-        if t.device != dev:
-            raise RuntimeError(f"{name} is on {t.device}, embeddings on {dev}: raw pointers cross the C ABI, all on one device")
+    _check_scalar_params(w, b, dev)
     if out is None:
         f32 = dict(dtype=torch.float32, device=dev)
         sc = torch.empty(3 if need_grad else 1, B, **f32)  # loss | dw | db in one allocation
@@ -339,10 +359,11 @@ def calc_loss(sim_matrix: torch.Tensor, *, eps: float = SMALL_ERR, variant: str 
 
 class _NormalizeUnpermFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, src):
+    def forward(ctx, y, src, unverified):
         lib = _lib.load()
         rows, D = y.shape
-        e = torch.empty_like(y)
+        e = torch.zeros_like(y) if unverified else torch.empty_like(y)
+        ctx.unverified = unverified
         rn = torch.empty(rows, dtype=torch.float32, device=y.device)
         with torch.cuda.device(y.device):
             code = lib.ge2e_normalize_unperm(y.data_ptr(), src.data_ptr() if src is not None else None, rows, D,
@@ -358,13 +379,13 @@ class _NormalizeUnpermFunction(torch.autograd.Function):
         e, rn, src = ctx.saved_tensors
         g = g.contiguous().float()
         rows, D = e.shape
-        dy = torch.empty_like(e)
+        dy = torch.zeros_like(e) if ctx.unverified else torch.empty_like(e)
         with torch.cuda.device(e.device):
             code = lib.ge2e_normalize_unperm_bwd(g.data_ptr(), e.data_ptr(), rn.data_ptr(),
                                                  src.data_ptr() if src is not None else None, rows, D, dy.data_ptr(),
                                                  _stream_ptr(e))
         _lib.check(code, "ge2e_normalize_unperm_bwd")
-        return dy, None
+        return dy, None, None
 
 
 def normalize_unperm(y: torch.Tensor, unperm=None, shape=None) -> torch.Tensor:
@@ -377,16 +398,19 @@ def normalize_unperm(y: torch.Tensor, unperm=None, shape=None) -> torch.Tensor:
         raise ValueError(f"y must be (rows, D), got {tuple(y.shape)}")
     rows = y.shape[0]
     src = _unperm_index(unperm, rows, y.device)
-    e = _NormalizeUnpermFunction.apply(y.contiguous().float(), src)
+    e = _NormalizeUnpermFunction.apply(y.contiguous().float(), src, _index_is_unverified(unperm))
     if shape is not None:
         e = e.reshape(*shape, e.shape[1])
     return e
 
 
 def _unperm_index(unperm, rows: int, device) -> Optional[torch.Tensor]:
-    """The reference's `unperm` (s4:183-186) as an int32 device tensor; a list is validated and travels through pinned
-    memory (no host sync on the step's critical path); a tensor is checked on the device only when GE2E_CHECK_INDEX=1
-    (the kernels write every output row exactly once only for a true permutation)."""
+    """The reference's `unperm` (s4:183-186) as an int32 device tensor.  A list is validated on the host and travels
+    through pinned memory (no host sync on the step's critical path).  A TENSOR cannot be validated without a sync, and
+    the kernels write every output row exactly once only for a true permutation; so for a tensor the outputs are
+    ZERO-initialised (`_index_is_unverified`) and the kernels skip entries outside range(rows): an index that is not a
+    permutation yields zero rows / zero gradients where nothing was written, never uninitialised memory and never an
+    out-of-range access.  `check_unperm` is the explicit (synchronising) test."""
     if unperm is None:
         return None
     if not torch.is_tensor(unperm):
@@ -395,13 +419,20 @@ def _unperm_index(unperm, rows: int, device) -> Optional[torch.Tensor]:
         return torch.tensor(unperm, dtype=torch.int32).pin_memory().to(device, non_blocking=True)
     if unperm.numel() != rows:
         raise ValueError("unperm must have one entry per row")
-    src = unperm.to(device=device, dtype=torch.int32).contiguous()
-    import os
-    if os.environ.get("GE2E_CHECK_INDEX") == "1":   # debug: one host sync
-        cnt = torch.bincount(src.clamp(0, rows - 1).long(), minlength=rows)
-        if bool((src < 0).any()) or bool((src >= rows).any()) or bool((cnt != 1).any()):
-            raise ValueError("unperm (tensor) is not a permutation of range(rows)")
-    return src
+    return unperm.to(device=device, dtype=torch.int32).contiguous()
+
+
+def _index_is_unverified(unperm) -> bool:
+    """True for an index the host has not validated (a tensor): outputs indexed through it are zero-initialised."""
+    return torch.is_tensor(unperm)
+
+
+def check_unperm(unperm: torch.Tensor, rows: int) -> None:
+    """Raises ValueError unless the tensor is a permutation of range(rows).  One host synchronisation."""
+    src = unperm.reshape(-1).long()
+    if src.numel() != rows or bool((src < 0).any()) or bool((src >= rows).any()) \
+            or bool((torch.bincount(src.clamp(0, rows - 1), minlength=rows) != 1).any()):
+        raise ValueError("unperm (tensor) is not a permutation of range(rows)")
 
 
 def raw_supported(N: int, M: int, D: int) -> bool:
@@ -413,14 +444,14 @@ class _GE2ELossRawFunction(torch.autograd.Function):
     """loss(normalize(y)[unperm].view(N,M,D)) and dL/dy in ONE launch (ge2e_loss_fwd_bwd_raw)."""
 
     @staticmethod
-    def forward(ctx, y, src, w, b, N, M, eps, eps_cos, variant):
+    def forward(ctx, y, src, w, b, N, M, eps, eps_cos, variant, unverified=False):
         lib = _lib.load()
         rows, D = y.shape
         dev = y.device
         need = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
         f32 = dict(dtype=torch.float32, device=dev)
         sc = torch.empty(3, **f32)                                   # loss | dw | db
-        dY = torch.empty_like(y) if need else None
+        dY = (torch.zeros_like(y) if unverified else torch.empty_like(y)) if need else None
         with _on_device(dev):
             code = lib.ge2e_loss_fwd_bwd_raw(
                 y.data_ptr(), src.data_ptr() if src is not None else None, 1, N, M, D, w.data_ptr(), b.data_ptr(),
@@ -451,7 +482,7 @@ class _GE2ELossRawFunction(torch.autograd.Function):
         _lib.check(code, "ge2e_scale_grads")
         gw = (gwb[0] if len(ctx.w_shape) == 0 else gwb[0].reshape(ctx.w_shape)) if need_w else None
         gb = (gwb[1] if len(ctx.b_shape) == 0 else gwb[1].reshape(ctx.b_shape)) if need_b else None
-        return gY, None, gw, gb, None, None, None, None, None
+        return gY, None, gw, gb, None, None, None, None, None, None
 
 
 def ge2e_loss_raw(y: torch.Tensor, unperm, w: torch.Tensor, b: torch.Tensor, shape, *, eps: float = SMALL_ERR,
@@ -468,7 +499,11 @@ def ge2e_loss_raw(y: torch.Tensor, unperm, w: torch.Tensor, b: torch.Tensor, sha
     if not raw_supported(N, M, y.shape[1]):
         return ge2e_loss(normalize_unperm(y, unperm, shape=(N, M)), w, b, eps=eps, eps_cos=eps_cos, variant=variant)
     src = _unperm_index(unperm, y.shape[0], y.device)
-    return _GE2ELossRawFunction.apply(y.contiguous().float(), src, w, b, N, M, float(eps), float(eps_cos), variant)
+    _check_scalar_params(w, b, y.device)
+    y = y.contiguous().float()
+    if y.data_ptr() % 16:          # a contiguous view at an odd storage offset: the kernels load 16 bytes per lane
+        y = y.clone()
+    return _GE2ELossRawFunction.apply(y, src, w, b, N, M, float(eps), float(eps_cos), variant, _index_is_unverified(unperm))
 
 
 def eer_counts(sim_matrix: torch.Tensor, thresholds) -> torch.Tensor:

@@ -41,12 +41,14 @@ class _AllGatherRows(torch.autograd.Function):
         world, rank = dist.get_world_size(ctx.group), dist.get_rank(ctx.group)
         grad = grad.contiguous()
         n = grad.shape[0] // world
-        out = torch.empty_like(grad[:n])
-        try:
-            dist.reduce_scatter(out, list(grad.split(n, dim=0)), op=dist.ReduceOp.SUM, group=ctx.group)
-        except (RuntimeError, NotImplementedError):   # backends without reduce_scatter (gloo): all-reduce, keep the own rows
+        # The collective is chosen ONCE from the group's backend, never from an exception: a rank that caught a genuine
+        # RCCL failure and switched to another collective would issue a different one from its peers (a hang or a
+        # mismatched collective instead of the error).  gloo has no reduce_scatter: all-reduce, keep the own rows.
+        if dist.get_backend(ctx.group) == "gloo":
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
-            out = grad[rank * n:(rank + 1) * n].clone()
+            return grad[rank * n:(rank + 1) * n].clone(), None
+        out = torch.empty_like(grad[:n])
+        dist.reduce_scatter_tensor(out, grad, op=dist.ReduceOp.SUM, group=ctx.group)
         return out, None
 
 

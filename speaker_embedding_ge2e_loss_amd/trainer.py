@@ -39,9 +39,9 @@ class DPTrainer:
         # shared_device: other streams or processes keep CUs of this GPU busy while the loss runs (communication overlapped
         # with the next step, several trainers on one device).  The loss's AUTO then leaves out the eight-CU team kernel,
         # whose workgroups wait for each other (impl "auto_no_team", include/ge2e_hip.h).  Not needed for this trainer's
-        # own collective: the all-reduce below is ordered between backward() and the next step's loss on the stream, so the
-        # two never run side by side (tests/test_trainer_nccl_single_rank.py: 200 steps on a real RCCL group, no hand-off
-        # time-out, no latency outlier).
+        # own collective: the all-reduce below is issued on the same stream between backward() and the next step's loss,
+        # so by stream order the two never run side by side (an argument from the ordering, not a measurement: the
+        # single-rank RCCL test only smoke-tests the code path).
         if shared_device and getattr(loss_module, "impl", None) == "auto":
             loss_module.impl = "auto_no_team"
         want_norm = not fused_tail
@@ -105,7 +105,11 @@ class DPTrainer:
         """embed + loss (s4:174-196).  With the fused tail and a shape the raw entry takes (the reference's own training
         shapes), normalise + un-permute + loss + their backward are ONE launch on the encoder's raw projection
         (functional.ge2e_loss_raw); otherwise embed() and the loss module."""
-        if self.fused_tail and getattr(self.ge2e_loss, "variant", None) is not None:
+        # the raw entry picks its own kernel and never runs the module's forward: only for a loss module that leaves the
+        # choice open (impl "auto" / "auto_no_team") and has no forward hooks registered
+        if self.fused_tail and getattr(self.ge2e_loss, "variant", None) is not None \
+                and getattr(self.ge2e_loss, "impl", "auto") in ("auto", "auto_no_team") \
+                and not self.ge2e_loss._forward_hooks and not self.ge2e_loss._forward_pre_hooks:
             from . import functional as GF
             n_spk, n_utt = mel.shape[0], mel.shape[1]
             d_out = getattr(self.model, "embedding_size", None)
@@ -136,10 +140,12 @@ class DPTrainer:
         return loss.detach()
 
     @torch.no_grad()
-    def eval_loss(self, mel_batches) -> float:
+    def eval_loss(self, mel_batches, require_batches: bool = False) -> float:
         """s4:61-110: mean over the test batches of the loss in eval mode (same perm/unperm, drawn
         from the same generator as the training steps, like the reference's global ``random``).
-        The per-batch losses stay on the device; there is ONE host read at the end."""
+        The per-batch losses stay on the device; there is ONE host read at the end.  An empty iterable gives NaN like
+        the reference's np.mean([]) -- or raises with ``require_batches`` (``fit`` asks for that, so that a NaN it sees
+        is a diverged loss and not an exhausted one-shot generator)."""
         was_training = self.model.training
         self.model.eval()       # s4:69
         losses = []
@@ -148,6 +154,8 @@ class DPTrainer:
         if was_training:
             self.model.train()  # s4:107
         if not losses:
+            if require_batches:
+                raise ValueError("test_batches yielded no batch (pass a re-iterable, not a one-shot generator)")
             return float("nan")  # np.mean([]) in the reference (s4:109)
         mean = torch.stack(losses).mean()
         if self.world > 1:      # every rank evaluated its own share of the test set
@@ -172,14 +180,16 @@ class DPTrainer:
 
     def fit(self, train_batches, epochs: int, test_batches=None, lr_reduce: int = 2000, epoch_print: int = 100,
             checkpoint_dir: Optional[str] = None, checkpoint_interval: int = 200, save_best_weights: bool = False,
-            min_test_loss: float = float("inf")):
+            min_test_loss: float = float("inf"), restore_existing_model: Optional[str] = None):
         """The epoch loop of s4:137-276 without its printing: per epoch the mean of the step losses
         (s4:215), every ``epoch_print`` epochs the batched test loss (s4:225-227), LR halving every
         ``lr_reduce`` epochs (s4:261-264), a checkpoint every ``checkpoint_interval`` (s4:266-267),
         a final one (s4:270) and, with ``save_best_weights``, the best test loss so far (s4:243-254).  ``train_batches`` is any re-iterable of (N,M,T,F) tensors.
         The step losses are reduced on the device: one host read per epoch instead of one per step
-        (s4:205)."""
+        (s4:205).  ``restore_existing_model``: path of an encoder-only checkpoint to start from (s4:24-30)."""
         import os
+        if restore_existing_model:      # hp.m_ge2e.restore_existing_model + model_path (s4:24-30): resume from an encoder-only file
+            self.load_checkpoint(restore_existing_model)
         self.model.train()
         train_losses, test_losses = [], []
         mean = float("nan")
@@ -194,10 +204,11 @@ class DPTrainer:
             mean = float(torch.stack(step_losses).mean())
             train_losses.append(mean)
             if test_batches is not None and (e + 1) % epoch_print == 0:
-                tl = self.eval_loss(test_batches)
-                if tl != tl:
-                    raise ValueError(f"epoch {e + 1}: test_batches yielded no batch (pass a re-iterable)")
-                test_losses.append(tl)
+                try:
+                    tl = self.eval_loss(test_batches, require_batches=True)
+                except ValueError as ex:
+                    raise ValueError(f"epoch {e + 1}: {ex}") from None
+                test_losses.append(tl)      # a NaN here is the model's own (diverged) test loss: recorded, like s4:227
                 # s4:243-254: hp.m_ge2e.save_best_weights -- a test loss under hp.m_ge2e.min_test_loss that is the best so
                 # far (ties included) is saved under the name "m_best"
                 if save_best_weights and checkpoint_dir is not None and tl < min_test_loss:

@@ -30,9 +30,19 @@ def test_gpus_2_spawns_two_ranks_train_step():
     assert "dp2" in j["config"]["parallelism"]
 
 
+def test_gpus_8_cfg4_train_step_dry_run():
+    """The configuration BASELINE names for the 8-GPU run (cfg4, data parallel, one flat-bucket all-reduce per step) with
+    eight ranks on CPU: the backend counts eight ranks in a real collective and every rank's clock reaches the line."""
+    j = run("--gpus", "8", "--mode", "train-step", "--config", "cfg4")
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and len(j["per_rank_value"]) == 8
+    assert j["config"]["N"] == 256 and "dp8" in j["config"]["parallelism"]
+    assert j["train_step"]["allreduce_busbw_GBs"] > 0
+
+
 def test_gpus_1_stays_one_process():
     j = run("--gpus", "1")
     assert j["n_gpus"] == 1 and j["config"]["batches_per_launch"] == 4096 and j["config"]["mode"] == "loss"
+    assert j["rccl_ranks"] == 1 and len(j["per_rank_value"]) == 1
 
 
 def test_bucket_is_the_reference_encoder_plus_w_b():

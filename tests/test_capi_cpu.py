@@ -86,9 +86,9 @@ def test_auto_leaves_the_team_kernel_out_on_request(lib):
         lib.ge2e_workspace_bytes(8, 64, 10, 256, 0, _lib.IMPLS["fused_split"])
 
 
-def test_environment_opt_out_is_read_once():
-    """GE2E_AUTO_NO_TEAM=1 in the environment turns every AUTO into auto_no_team; it is read ONCE per process (not per
-    call), so it is checked in a child process."""
+def test_no_environment_override_of_the_implementation_choice():
+    """Rounds 2-3 honoured GE2E_AUTO_NO_TEAM=1; the choice is an argument of the call now (impl="auto_no_team") and the
+    variable changes nothing."""
     import subprocess
     import sys
     code = ("from speaker_embedding_ge2e_loss_amd import _lib; lib = _lib.load(); "
@@ -97,7 +97,7 @@ def test_environment_opt_out_is_read_once():
     env = dict(os.environ, GE2E_AUTO_NO_TEAM="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr
-    assert int(out.stdout.strip().splitlines()[-1]) == _lib.IMPLS["fused_split"]
+    assert int(out.stdout.strip().splitlines()[-1]) == _lib.IMPLS["team"]
 
 
 def test_product_refuses_cpu_tensors():

@@ -59,3 +59,40 @@ def test_back_to_back_replays_keep_the_teams():
     assert torch.equal(step.loss, first) and torch.equal(step.input_grad, g0)   # bitwise deterministic
     med = float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(200)])) * 1e3
     assert med < 90.0, f"{med:.1f} us per replayed step: the one-workgroup-per-batch fall-back alone takes 120 us"
+
+
+def test_workspace_cache_and_capture_on_one_stream():
+    """ADVICE (round 3): eager warm-up and capture on the SAME stream, then a larger eager call on it (which replaces the
+    cached workspace), then replays.  A graph that had baked in the cached workspace pointer would now write its team
+    control block and exchange area into memory the allocator has handed out again; the workspace of a captured launch
+    must come from the graph's own pool instead.  Also: two graphs captured one after the other must not share one."""
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+
+    dev = torch.device("cuda:0")
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    e1 = torch.as_tensor(orc.synth_embeddings((2, 64, 10, 256), "unit", seed=41), device=dev)
+    e2 = torch.as_tensor(orc.synth_embeddings((2, 64, 10, 256), "unit", seed=42), device=dev)
+    big = torch.as_tensor(orc.synth_embeddings((300, 64, 10, 256), "unit", seed=43), device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    outs, graphs = [], []
+    with torch.cuda.stream(side):
+        for e in (e1, e2):
+            for _ in range(2):
+                GF.loss_fwd_bwd(e, w, b, impl="team")                      # eager warm-up: fills the (device, stream) cache
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                o = GF.loss_fwd_bwd(e, w, b, impl="team")
+            graphs.append(g)
+            outs.append(o)
+        ref = [GF.loss_fwd_bwd(e, w, b, impl="team") for e in (e1, e2)]
+        GF.loss_fwd_bwd(big, w, b, impl="team")                            # larger need on the same stream: cache entry replaced
+        junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(8)]   # whatever was freed gets reused
+        for _ in range(3):
+            for g in graphs:
+                g.replay()
+        side.synchronize()
+    del junk
+    for o, r in zip(outs, ref):
+        assert torch.equal(o.loss, r.loss) and torch.equal(o.dE, r.dE) and torch.equal(o.dw, r.dw)
+    assert len(GF._ws_cache) <= GF._WS_CACHE_MAX

@@ -60,7 +60,10 @@ def run_hip(GF, E, w, b, variant="softmax", impl="auto", eps=1e-6):
     return {k: squeeze(getattr(o, k)).cpu().numpy() for k in ("loss", "per", "dE", "dw", "db")}
 
 
-def check(o, ref, impl, what=""):
+def check(o, ref, impl, what="", strict=False):
+    """strict = the BASELINE configs and the reference's own fixtures: the stated gate with no per-row floors --
+    db atol 1e-4 flat, dw rtol + 1e-5.  The floors that scale with the row count are for fuzz / ragged shapes only, where
+    dw and db are sums of thousands of terms of both signs that cancel to ~0."""
     lt, gt, wt, _ = TOL[impl]
     loss_ref = np.asarray(ref["loss"], np.float64)
     # loss is a sum of NM terms of size ~|S|: fp32 noise floor scales with that, not with |loss|
@@ -76,8 +79,10 @@ def check(o, ref, impl, what=""):
     assert np.abs(o["dE"] - ref["dE"]).max() <= 4 * gt * scale, f"{what} dE max-abs"
     dw_ref = np.asarray(ref["dw"], np.float64)
     # dw = sum G (cos + eps) cancels when the rows' terms have both signs: an absolute floor per row beside the relative bound
-    assert np.all(np.abs(o["dw"] - dw_ref) <= wt * np.abs(dw_ref) + 1e-5 + 1e-7 * nm), f"{what} dw {o['dw']} vs {dw_ref}"
-    assert np.allclose(o["db"], ref["db"], atol=1e-4 + 3e-7 * nm), f"{what} db"   # db cancels row by row: an fp32 floor per row
+    rowfloor = 0.0 if strict else 1.0
+    assert np.all(np.abs(o["dw"] - dw_ref) <= wt * np.abs(dw_ref) + 1e-5 + 1e-7 * nm * rowfloor), f"{what} dw {o['dw']} vs {dw_ref}"
+    # db cancels row by row: an fp32 floor per row -- for the non-BASELINE shapes only
+    assert np.allclose(o["db"], ref["db"], rtol=0, atol=1e-4 + 3e-7 * nm * rowfloor), f"{what} db {o['db']} vs {ref['db']}"
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -93,7 +98,7 @@ def test_golden_vectors(GF, name):
             assert np.abs(o["dE"] - ref["dE"]).max() <= 1e-5 * np.abs(ref["dE"]).max()
             assert np.allclose(o["loss"], ref["loss"], rtol=1e-5)
             continue
-        check(o, ref, impl, f"{name}/{impl}")
+        check(o, ref, impl, f"{name}/{impl}", strict=True)
         # and against the reference's own fp32 run, at the north-star tolerance
         assert np.allclose(o["loss"], g["loss"], rtol=1e-4, atol=1e-5)
         assert rel_fro(o["dE"], g["dE"]) <= 1e-4
@@ -114,7 +119,7 @@ def test_baseline_configs_vs_oracle(GF, cfg, kind):
     E = orc.synth_embeddings((B, N, M, D), kind, seed=1234)
     ref = orc.closed_form(E, 10.0, -5.0, variant=variant)
     for impl in impls_for(GF, B, N, M, D, variant):
-        check(run_hip(GF, E, 10.0, -5.0, variant, impl), ref, impl, f"{cfg}/{kind}/{impl}")
+        check(run_hip(GF, E, 10.0, -5.0, variant, impl), ref, impl, f"{cfg}/{kind}/{impl}", strict=True)
 
 
 def test_config5_large(GF):
@@ -123,7 +128,17 @@ def test_config5_large(GF):
     E = orc.synth_embeddings((B, N, M, D), "clustered", seed=5)
     ref = orc.closed_form(E, 10.0, -5.0)
     o = run_hip(GF, E, 10.0, -5.0, impl="auto")
-    check(o, ref, "auto", "cfg5")
+    check(o, ref, "auto", "cfg5", strict=True)
+
+
+def test_config5_benched_launch_sampled(GF):
+    """cfg5 at the launch size bench.py times (B = 16): sampled batches against the fp64 closed form."""
+    B, N, M, D = 16, 1024, 10, 768
+    E = orc.synth_embeddings((B, N, M, D), "unit", seed=11)
+    o = run_hip(GF, E, 10.0, -5.0, impl="auto")
+    for i in (0, 7, 15):
+        ref = orc.closed_form(E[i], 10.0, -5.0)
+        check({k: v[i] for k, v in o.items()}, ref, "auto", f"cfg5 B=16 batch {i}", strict=True)
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 2, 1), (1, 2, 2, 3), (3, 5, 3, 7), (2, 7, 4, 65), (1, 65, 2, 33),

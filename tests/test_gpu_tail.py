@@ -115,3 +115,34 @@ def test_loss_raw_falls_back_outside_the_wave_shapes():
     w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
     loss = GF.ge2e_loss_raw(y.to(dev), None, w, b, (N, M))
     assert np.allclose(loss.item(), ref["loss"], rtol=2e-5)
+
+
+def test_tensor_index_that_is_no_permutation_leaves_zeros_not_garbage():
+    """A tensor `unperm` cannot be validated without a host sync; the outputs it indexes are zero-initialised and the
+    kernels skip entries outside the range, so a bad index gives zero rows / zero gradients where nothing was written --
+    never uninitialised memory, never an out-of-range access (hygiene)."""
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+    dev = torch.device("cuda:0")
+    rows, D = 20, 256
+    torch.full((1 << 22,), float("nan"), device=dev)        # poison the allocator's free blocks
+    y = torch.randn(rows, D, device=dev, requires_grad=True)
+    bad = torch.arange(rows, device=dev, dtype=torch.int32)
+    bad[3] = rows + 5        # out of range: output row 3 is never written
+    bad[7] = -2
+    bad[9] = 8               # a repeat: row 9 of y is never read, its gradient is never written
+    e = GF.normalize_unperm(y, bad)
+    e.sum().backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(e).all()) and bool((e[3] == 0).all()) and bool((e[7] == 0).all())
+    assert bool(torch.isfinite(y.grad).all()) and bool((y.grad[9] == 0).all())
+    with pytest.raises(ValueError):
+        GF.check_unperm(bad, rows)
+    GF.check_unperm(torch.randperm(rows, device=dev), rows)
+    # the one-launch raw entry (wave kernel): same index through the gather / scatter of ge2e_loss_fwd_bwd_raw
+    y2 = torch.randn(rows, D, device=dev, requires_grad=True)
+    w = torch.tensor(10.0, device=dev, requires_grad=True)
+    b = torch.tensor(-5.0, device=dev, requires_grad=True)
+    loss = GF.ge2e_loss_raw(y2, bad, w, b, (4, 5))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(y2.grad).all()) and bool((y2.grad[9] == 0).all())

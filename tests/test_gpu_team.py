@@ -219,6 +219,26 @@ def test_benched_launch_size(GF, impl):
     assert float((num / den).max()) < 5e-6
 
 
+@pytest.mark.parametrize("impl", ("team", "auto"))
+def test_forward_only_at_the_benched_launch_size(GF, impl):
+    """bench.py's forward_only leg: B = 4096 at the metric shape with dE = NULL (similarity + loss, s4:61-110 /
+    s5:42-44).  loss and per-row losses: all finite, equal to the fwd+bwd launch's, sampled batches against the oracle."""
+    B, N, M, D = 4096, 64, 10, 256
+    e = _device_batches(B, N, M, D, 78)
+    w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda:0")  # noqa: E731
+    of = GF.loss_fwd_bwd(e, w, b, impl=impl, need_grad=False,
+                         out=GF.LossOutputs(loss=nan(B), per=nan(B, N, M), dE=None, dw=None, db=None))
+    og = GF.loss_fwd_bwd(e, w, b, impl=impl, need_per=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(of.loss).all()) and bool(torch.isfinite(of.per).all())
+    assert torch.equal(of.loss, og.loss) and torch.equal(of.per, og.per)     # the same forward arithmetic, bit for bit
+    for i in (0, 31, 32, 2048, 4095):
+        ref = orc.closed_form(e[i].cpu().numpy(), 10.0, -5.0, want_grad=False)
+        assert abs(float(of.loss[i]) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), i
+        assert np.abs(of.per[i].cpu().numpy() - ref["per"]).max() <= 2e-5 * max(1.0, np.abs(ref["per"]).max()), i
+
+
 @pytest.mark.parametrize("shape,per_team", [((16, 4, 64), 1100), ((64, 10, 256), 1000)])
 def test_thousand_batches_through_one_team(GF, shape, per_team):
     """The launch capped to 64 workgroups = one team per XCD (ge2e_selftest_team_grid): every team works through a

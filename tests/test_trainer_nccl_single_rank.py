@@ -1,9 +1,12 @@
 """GPU: DPTrainer.step on a REAL RCCL process group (one rank, backend "nccl") with the loss's AUTO choice, i.e. the
-eight-CU team kernel at the metric shape with B = 1, next to the flat-bucket all-reduce of every step.
+eight-CU team kernel at the metric shape with B = 1, followed by the flat-bucket all-reduce of every step.
 
-What it retires without an 8-GPU node (s4:196-203): the team kernel's workgroups wait for each other, so a collective
-kernel that held CUs at the wrong moment would show up as a hand-off time-out (the abort word in the workspace's control
-block, after which the in-call fall-back launch redoes the batch) or as a latency outlier.  200 steps; neither may happen."""
+A smoke test of the code path of s4:196-203 on the nccl backend -- NOT evidence about multi-rank overlap: a one-rank
+all-reduce is a copy / no-op rather than a ring kernel that holds CUs, and it is stream-ordered behind backward() anyway.
+What it does show: 200 trainer steps through the RCCL API with the team kernel in every one, the abort word in the
+workspace's control block never raised, no latency outlier.  The team kernel beside a kernel that really occupies CUs on
+another stream is tests/test_gpu_team.py::test_team_beside_a_busy_stream (a filler kernel, not RCCL); N > 1 ranks on
+hardware is the driver's measurement."""
 import os
 import socket
 import time
