@@ -5,11 +5,12 @@
 //
 //   k_prep    per speaker : sums, c-hat -> CH images + fp32 copy; per row: 1/|e|, e-hat -> EH images
 //   k_sim     X = EH . CH^T                    tiles (64 rows x 64 centroids), K = D      (s3:64-70)
-//   k_rows    per row     : leave-one-out cosine from X's own column, S, loss, G_off -> GH images,
-//                           row coefficients of the gradient                              (s3:27, 115-127)
+//   k_rows    per row     : leave-one-out cosine from X's own column, S, loss, dL/dS -> GH images (the own-speaker
+//                           column carries the coefficient of s_j), row coefficients of the gradient  (s3:27, 115-127)
 //   k_gc      gC = GH^T . EH                   tiles (64 centroids x 64 d), K = all N*M rows
-//   k_spk     per speaker : gC through the centroid norm, + leave-one-out sums -> KJ rows
-//   k_ge      gE = GH . CH, epilogue dE = ra gE + c1e e + rc c-hat_j + KJ_j
+//   k_spk     per speaker : gC through the centroid norm + a multiple of c-hat_j -> KJ rows (the leave-one-out speaker row
+//                           sum_i c3_i e-hat_i is already in gC_j through GH's own column: no second pass over the rows)
+//   k_ge      gE = GH . CH, epilogue dE = ra gE + c1e e + KJ_j
 //   k_reduce  loss / dw / db: fixed-order sum of the per-row values
 //
 // Shapes: D % 64 == 0, D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
@@ -440,6 +441,8 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
             }
     }
     float dwv = 0.f, dbv = 0.f, coef = 0.f, ad = 0.f;
+    const float rho_ = rnu * inv_m1, t1_ = ku * cosd * rho_;
+    const float own_o = rho_ * (rne + t1_) * cs.z / rne;     // o / (dL/dS on the own column)
     _Float16* GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r * npad;
     _Float16* GHl = GHh + (size_t)NM * npad;
 #pragma unroll
@@ -454,7 +457,10 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
                 dwv += gv[e] * (c0[c][e] + eps);
                 dbv += gv[e];
                 coef += gv[e] * c0[c][e];
-                if (k == j) { ad = gv[e]; gv[e] = 0.f; }
+                // the own-speaker column carries o = c2 |s_j| / (ra w): k_ge's contraction then adds the c2 s_j term of dE
+                // by itself, and what o adds to gC_j is, pushed through the centroid norm in k_spk, exactly the
+                // leave-one-out speaker row sum_i c3_i e-hat_i minus kap_j (sum_i c3_i xo_i) c-hat_j (ge2e_team.hip, S)
+                if (k == j) { ad = gv[e]; gv[e] = own_o * gv[e]; }
             }
             h4 hi, lo;
             split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
@@ -471,8 +477,9 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
         const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne);
         const float beta = -ad * rnu * ku * cosd * rho;
         float* rs = p.ws + L.rs + gr * 8;
-        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, c2 * cs.z, alpha * inv_m1);
-        *reinterpret_cast<float4*>(rs + 4) = make_float4(beta * inv_m1, per, dwv, dbv);
+        // ra, c1e; then the row's share of the c-hat_j coefficient of KJ_j: c4' = (beta |s_j| + kap_j alpha xo) / (M - 1)
+        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, 0.f, 0.f);
+        *reinterpret_cast<float4*>(rs + 4) = make_float4(inv_m1 * (beta * cs.z + cs.y * alpha * xo), per, dwv, dbv);
         if (p.per) p.per[gr] = per;
     }
 }
@@ -556,6 +563,8 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
             }
     }
     float dwv = 0.f, dbv = 0.f, coef = 0.f, ad = 0.f;
+    const float rho_ = rnu * inv_m1, t1_ = ku * cosd * rho_;
+    const float own_o = rho_ * (rne + t1_) * cs.z / rne;     // o / (dL/dS on the own column)
     _Float16* GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r * npad;
     _Float16* GHl = GHh + (size_t)NM * npad;
 #pragma unroll
@@ -570,7 +579,10 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
                 dwv += gv[e] * (c0[c][e] + eps);
                 dbv += gv[e];
                 coef += gv[e] * c0[c][e];
-                if (k == j) { ad = gv[e]; gv[e] = 0.f; }
+                // the own-speaker column carries o = c2 |s_j| / (ra w): k_ge's contraction then adds the c2 s_j term of dE
+                // by itself, and what o adds to gC_j is, pushed through the centroid norm in k_spk, exactly the
+                // leave-one-out speaker row sum_i c3_i e-hat_i minus kap_j (sum_i c3_i xo_i) c-hat_j (ge2e_team.hip, S)
+                if (k == j) { ad = gv[e]; gv[e] = own_o * gv[e]; }
             }
             h4 hi, lo;
             split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
@@ -589,8 +601,9 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
         const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne);
         const float beta = -ad * rnu * ku * cosd * rho;
         float* rs = p.ws + L.rs + gr * 8;
-        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, c2 * cs.z, alpha * inv_m1);
-        *reinterpret_cast<float4*>(rs + 4) = make_float4(beta * inv_m1, per, dwv, dbv);
+        // ra, c1e; then the row's share of the c-hat_j coefficient of KJ_j: c4' = (beta |s_j| + kap_j alpha xo) / (M - 1)
+        *reinterpret_cast<float4*>(rs) = make_float4(rne * (w * kSplitInv2), c1 * rne, 0.f, 0.f);
+        *reinterpret_cast<float4*>(rs + 4) = make_float4(inv_m1 * (beta * cs.z + cs.y * alpha * xo), per, dwv, dbv);
         if (p.per) p.per[gr] = per;
     }
 }
@@ -650,8 +663,6 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
     const float* GC = p.ws + L.gc + ((size_t)bi * N + j) * D;
     const float* CHf = p.ws + L.chf + ((size_t)bi * N + j) * D;
     const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);
-    const _Float16* EHh = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + (size_t)j * M * D;
-    const _Float16* EHl = EHh + (size_t)NM * D;
     const float* RS = p.ws + L.rs + ((size_t)bi * NM + (size_t)j * M) * 8;
     float* KJ = p.ws + L.kj + ((size_t)bi * N + j) * D;
     const int npass = (D + 255) >> 8;
@@ -671,20 +682,14 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
     const float f = cs.y * coef, sc = cs.x / fM;
     float bsum = 0.f;
     for (int i = 0; i < M; ++i) bsum += RS[i * 8 + 4];
-    const float bs = bsum * cs.z;
+    const float bs = bsum;      // sum_i c4'_i: the whole speaker row KJP_j is a multiple of c-hat_j (the e-hat part rides in gC)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d = 256 * q + 4 * lane;
         if (q < npass && d < D) {
-            float4 acc = make_float4((g[q].x - f * c[q].x) * sc + bs * c[q].x, (g[q].y - f * c[q].y) * sc + bs * c[q].y,
-                                     (g[q].z - f * c[q].z) * sc + bs * c[q].z, (g[q].w - f * c[q].w) * sc + bs * c[q].w);
-            for (int i = 0; i < M; ++i) {
-                const float c3 = RS[i * 8 + 3] * kSplitInv;
-                const float4 e = join4(*reinterpret_cast<const h4*>(EHh + (size_t)i * D + d),
-                                       *reinterpret_cast<const h4*>(EHl + (size_t)i * D + d));
-                acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
-            }
-            *reinterpret_cast<float4*>(KJ + d) = acc;
+            *reinterpret_cast<float4*>(KJ + d) =
+                make_float4((g[q].x - f * c[q].x) * sc + bs * c[q].x, (g[q].y - f * c[q].y) * sc + bs * c[q].y,
+                            (g[q].z - f * c[q].z) * sc + bs * c[q].z, (g[q].w - f * c[q].w) * sc + bs * c[q].w);
         }
     }
     // the batch's loss / dw / db: fixed-order sums of the per-row values (k_rows wrote them two launches ago), taken by
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
 
 // ---------------------------------------------------------------------------------------------
 // k_ge: gE[r][d] = sum_k GH[r][k] CH[k][d] per (TM rows x TN d) tile (A K-contiguous, B K-rows), then the epilogue
-// dE = ra gE + c1e e + rc c-hat_j + KJ_j.
+// dE = ra gE + c1e e + KJ_j (the c2 s_j term rides in GH's own-speaker column).
 template <class C>
 __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) {
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
@@ -730,7 +735,6 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
     gemm_tile<C, true, false>(A, Bo, N, gsm, tid, acc);   // K = the N real centroid slots (pad columns of GH are zero)
     const float* E = p.E + (size_t)bi * NM * D;
     float* dE = p.dE + (size_t)bi * NM * D;
-    const float* CHf = p.ws + L.chf + (size_t)bi * N * D;
     const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
     const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
     // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
             const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
             const bool rv = r < NM;
             const int rc = rv ? r : NM - 1;
-            const float4 rs = *reinterpret_cast<const float4*>(RS + (size_t)rc * 8);  // ra c1e c2s c3
+            const float2 rs = *reinterpret_cast<const float2*>(RS + (size_t)rc * 8);  // ra c1e
             const int j = rc / M;
 #pragma unroll
             for (int b2 = 0; b2 < C::B2; ++b2) {
@@ -752,11 +756,10 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
                 const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
                 if (rv && d < D) {
                     const float4 e = *reinterpret_cast<const float4*>(E + (size_t)r * D + d);
-                    const float4 c = *reinterpret_cast<const float4*>(CHf + (size_t)j * D + d);
                     const float4 kj = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + d);
                     *reinterpret_cast<float4*>(dE + (size_t)r * D + d) =
-                        make_float4(x[0] * rs.x + e.x * rs.y + c.x * rs.z + kj.x, x[1] * rs.x + e.y * rs.y + c.y * rs.z + kj.y,
-                                    x[2] * rs.x + e.z * rs.y + c.z * rs.z + kj.z, x[3] * rs.x + e.w * rs.y + c.w * rs.z + kj.w);
+                        make_float4(x[0] * rs.x + e.x * rs.y + kj.x, x[1] * rs.x + e.y * rs.y + kj.y,
+                                    x[2] * rs.x + e.z * rs.y + kj.z, x[3] * rs.x + e.w * rs.y + kj.w);
                 }
             }
         }
