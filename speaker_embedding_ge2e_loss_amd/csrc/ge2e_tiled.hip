@@ -83,7 +83,12 @@ struct GemmCfg {
     static constexpr int NP = KS / 16;                             // 16-byte pieces per plane per thread (= T * KS / 8 / NT)
     static constexpr int PLANE_A = TM_ * KP > KS * (TM_ + 16) ? TM_ * KP : KS * (TM_ + 16);
     static constexpr int PLANE_B = TN_ * KP > KS * (TN_ + 16) ? TN_ * KP : KS * (TN_ + 16);
-    static constexpr size_t LDS_BYTES = (size_t)2 * (PLANE_A + PLANE_B) * sizeof(_Float16);
+    // The big tile runs with TWO LDS stages (2 x 80 KB = the whole 160 KB, one workgroup per CU either way): the operands of
+    // K-step s + 1 are written to the other stage behind the MFMAs of step s -- one barrier per K-step and no write phase in
+    // which the matrix pipe idles.  The small tile keeps one stage (74 KB) so that two workgroups share a CU.
+    static constexpr int STAGES = TM_ == 256 ? 2 : 1;
+    static constexpr int STAGE_HALFS = 2 * (PLANE_A + PLANE_B);
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_HALFS * sizeof(_Float16);
 };
 
 struct Opnd {
@@ -139,15 +144,55 @@ template <class C, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
                                           f32x16 (&acc)[C::A2][C::B2]) {
     constexpr int KS = C::KS;
-    _Float16* const Ah = sm;
-    _Float16* const Al = sm + C::PLANE_A;
-    _Float16* const Bh = sm + 2 * C::PLANE_A;
-    _Float16* const Bl = Bh + C::PLANE_B;
     const int lane = tid & 63, wid = tid >> 6, wa = wid / C::WN, wb = wid % C::WN;
     const int arow0 = wa * (32 * C::A2), bcol0 = wb * (32 * C::B2);
     uint4 pah[C::NP], pal[C::NP], pbh[C::NP], pbl[C::NP];
     gemm_fetch<C, AKC, C::TM>(A, 0, min(KS, ktotal), tid, pah, pal);
     gemm_fetch<C, BKC, C::TN>(B, 0, min(KS, ktotal), tid, pbh, pbl);
+    if constexpr (C::STAGES == 2) {
+        gemm_stash<C, AKC, C::TM>(sm, sm + C::PLANE_A, tid, pah, pal);
+        gemm_stash<C, BKC, C::TN>(sm + 2 * C::PLANE_A, sm + 2 * C::PLANE_A + C::PLANE_B, tid, pbh, pbl);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = 0; k0 < ktotal; k0 += KS, cur ^= 1) {
+            const _Float16* const Ah = sm + cur * C::STAGE_HALFS;
+            const _Float16* const Al = Ah + C::PLANE_A;
+            const _Float16* const Bh = Ah + 2 * C::PLANE_A;
+            const _Float16* const Bl = Bh + C::PLANE_B;
+            const bool more = k0 + KS < ktotal;
+            if (more) {   // next K-step's operands: in flight under the MFMAs below
+                gemm_fetch<C, AKC, C::TM>(A, k0 + KS, min(KS, ktotal - k0 - KS), tid, pah, pal);
+                gemm_fetch<C, BKC, C::TN>(B, k0 + KS, min(KS, ktotal - k0 - KS), tid, pbh, pbl);
+            }
+#pragma unroll
+            for (int s = 0; s < KS / 16; ++s) {
+                h8 bh[C::B2], bl[C::B2];
+#pragma unroll
+                for (int u = 0; u < C::B2; ++u) {
+                    bh[u] = gemm_frag<C, BKC, C::TN>(Bh, bcol0 + 32 * u, s, lane);
+                    bl[u] = gemm_frag<C, BKC, C::TN>(Bl, bcol0 + 32 * u, s, lane);
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < C::A2; ++a2) {
+                    const h8 ah = gemm_frag<C, AKC, C::TM>(Ah, arow0 + 32 * a2, s, lane);
+                    const h8 al = gemm_frag<C, AKC, C::TM>(Al, arow0 + 32 * a2, s, lane);
+#pragma unroll
+                    for (int b2 = 0; b2 < C::B2; ++b2) acc[a2][b2] = mfma3(ah, al, bh[b2], bl[b2], acc[a2][b2]);
+                }
+            }
+            if (more) {   // ... and into the OTHER stage, which nobody has read since the barrier of the previous step
+                _Float16* const nA = sm + (cur ^ 1) * C::STAGE_HALFS;
+                gemm_stash<C, AKC, C::TM>(nA, nA + C::PLANE_A, tid, pah, pal);
+                gemm_stash<C, BKC, C::TN>(nA + 2 * C::PLANE_A, nA + 2 * C::PLANE_A + C::PLANE_B, tid, pbh, pbl);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    _Float16* const Ah = sm;
+    _Float16* const Al = sm + C::PLANE_A;
+    _Float16* const Bh = sm + 2 * C::PLANE_A;
+    _Float16* const Bl = Bh + C::PLANE_B;
     for (int k0 = 0; k0 < ktotal; k0 += KS) {
         gemm_stash<C, AKC, C::TM>(Ah, Al, tid, pah, pal);
         gemm_stash<C, BKC, C::TN>(Bh, Bl, tid, pbh, pbl);
