@@ -262,7 +262,9 @@ size_t team_workspace_bytes(int B, int N, int M, int D) {
 // ---------------------------------------------------------------------------------------------
 // D = 64 * NCH; MR >= M rows of a speaker are prefetched into registers; RBT > 0: the member's images have exactly
 // RBT 16-row blocks (compile-time trip counts for the metric shape), RBT == 0: L.rt / 16 at run time.
-template <int NCH, int MR, int RBT, bool CONTRAST>
+// FWD: the forward-only instantiation of the metric shape (similarity + loss, dE == NULL known at compile time: no held /
+// fragment / partial-gradient registers, no gradient phases in the loop at all).
+template <int NCH, int MR, int RBT, bool CONTRAST, bool FWD = false>
 __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     const float eps_cos2 = eps_cos * eps_cos;                                                  \
     const float fM = (float)mc_, inv_m = rcp_nr(fM), inv_m1 = rcp_nr((float)(mc_ - 1));       \
     (void)w; (void)bias; (void)eps_cos2; (void)fM; (void)inv_m; (void)inv_m1; (void)le_
-    const bool want_grad = p.dE != nullptr;
+    const bool want_grad = !FWD && p.dE != nullptr;
     const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + XO.chr[buf], 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, 0);
             }
-            if (dact) {   // one 8-byte write per image: a row of the stage per wave
+            if (dact && want_grad) {   // one 8-byte write per image: a row of the stage per wave (the k-group form is gE's operand)
                 *reinterpret_cast<h4*>(STG + wid * SP + d4) = hi;
                 *reinterpret_cast<h4*>(STG + (8 + wid) * SP + d4) = lo;
             }
@@ -452,9 +454,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
                                     make_float4(rn, kap, has_spk ? fM * nc : 0.f, has_spk ? ss : 0.f));
         }
         GE2E_PROF_SUB(15);
-        __syncthreads();
+        if (want_grad) __syncthreads();      // (forward only: no stage, no k-group form -- one barrier and 64 KB of exchange fewer per batch)
         GE2E_PROF_SUB(16);
-        if (have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d), gathered
+        if (want_grad && have_cur && tid < 2 * D) {   // the k-group form: 16 bytes (this member's 8 slots) per (hi / lo, d), gathered
             // by the transposing LDS read (4 slots x 16 columns per 16 lanes, twice); whole waves only (2 D % 64 == 0)
             const int hl = tid >= D, d = tid - hl * D;
             const int l16 = tid & 15;
@@ -1069,9 +1071,9 @@ __global__ __launch_bounds__(256) void team_zero_head(uint4* head, int n16, int 
     }
 }
 
-template <int NCH, int MR, int RBT, bool CONTRAST>
+template <int NCH, int MR, int RBT, bool CONTRAST, bool FWD = false>
 static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST>);
+    const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST, FWD>);
     static KernelLaunchState state;     // one per instantiation; per-device entries inside
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, (unsigned)L.lds_bytes, &nb);
@@ -1093,13 +1095,16 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     if (p.grid_cap > 0 && p.grid_cap < grid)      // diagnostics: fewer teams, more batches through each (whole XCD rounds)
         grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;
     if (nb < 1 || grid > nb * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST, FWD>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
     return hipGetLastError();
 }
 template <int NCH, int MR>
 static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
-    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64)   // the metric shape: compile-time N, M, trip counts
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64) {   // the metric shape: compile-time N, M, trip counts
+        if (p.dE == nullptr)    // ... and its forward-only form (evaluation: s4:61-110, s5:42-44)
+            return p.variant == 1 ? launch_nch<4, 10, 5, true, true>(p, L, stream) : launch_nch<4, 10, 5, false, true>(p, L, stream);
         return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
+    }
     return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
 }
 

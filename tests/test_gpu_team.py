@@ -232,7 +232,9 @@ def test_forward_only_at_the_benched_launch_size(GF, impl):
     og = GF.loss_fwd_bwd(e, w, b, impl=impl, need_per=True)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(of.loss).all()) and bool(torch.isfinite(of.per).all())
-    assert torch.equal(of.loss, og.loss) and torch.equal(of.per, og.per)     # the same forward arithmetic, bit for bit
+    # the forward-only launch is an instantiation of its own (no gradient code compiled in): same arithmetic, but the
+    # compiler may contract an fma differently -- last-bit agreement, not bitwise
+    assert torch.allclose(of.loss, og.loss, rtol=1e-6) and torch.allclose(of.per, og.per, rtol=2e-6, atol=2e-6)
     for i in (0, 31, 32, 2048, 4095):
         ref = orc.closed_form(e[i].cpu().numpy(), 10.0, -5.0, want_grad=False)
         assert abs(float(of.loss[i]) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), i
