@@ -378,13 +378,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         g[i] = (i == jrel) ? -pos * (1.0f - pos) : ((8 * qk + i == besti) ? neg * (1.0f - neg) : 0.f);
                 }
                 float coef = 0.f, ad = 0.f;
+                const float rho_o = rnu * inv_m1;
+                const float own_o = rv ? rho_o * (rne1 + ku * cosd * rho_o) * cs.z / rne1 : 0.f;   // o / (dL/dS on the own column)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (!rv || 8 * qk + i >= N) g[i] = 0.f;
                     dw_acc += g[i] * (c0[i] + eps);
                     db_acc += g[i];
                     coef += g[i] * c0[i];           // (dL/d e-hat) . e-hat / w, own-speaker term included
-                    if (i == jrel) { ad = g[i]; g[i] = 0.f; }
+                    // the own-speaker column carries o = c2 |s_j| / (ra w): sweep 3's contraction adds the c2 s_j term of dE by
+                    // itself, and what o adds to gC_j is, pushed through the centroid norm, exactly the leave-one-out speaker
+                    // row sum_i c3_i e-hat_i minus kap_j (sum_i c3_i xo_i) c-hat_j (ge2e_team.hip, S): no second pass over the
+                    // e-hat images for KJP_j
+                    if (i == jrel) { ad = g[i]; g[i] *= own_o; }
                 }
                 coef = w * oct_sum(coef);
                 ad = w * oct_sum(ad);               // dL/dcos on the own-speaker column
@@ -416,38 +422,25 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                     const float c1 = (-ke * coef * rne1 - ad * rnu * inv_m1) - c2 / rne1;
                     const float alpha = ad * rnu * (1.0f + ku * cosd * rho / rne1);
                     const float beta = -ad * rnu * ku * cosd * rho;
-                    if (qk == 0) {   // c3, c4: coefficients of e-hat_i and s_j in the speaker's KJ row
-                        RS[rl * 8 + 4] = rv ? alpha * inv_m1 : 0.f;
-                        RS[rl * 8 + 5] = rv ? beta * inv_m1 : 0.f;
-                    }
+                    if (qk == 0)     // c4': the row's share of the c-hat_j coefficient of the speaker's KJ row
+                        RS[rl * 8 + 5] = rv ? inv_m1 * (beta * cs.z + cs.y * alpha * xo) : 0.f;
                     const unsigned vr = (qk == 0) ? (unsigned)((t * TR + rl) * 16) : OOB;
-                    bstore4(rsW, vr, offR, make_float4(rne * (w * kSplitInv2), c1 * rne,
-                                                       rv ? c2 * cs.z * kSplitInv : 0.f, __int_as_float(j)));
+                    bstore4(rsW, vr, offR, make_float4(rne * (w * kSplitInv2), c1 * rne, 0.f, __int_as_float(j)));
                 }
             }
             __syncthreads();
             GE2E_PROF(3);
 
-            // -- (d0) per-speaker rows KJP_j = sum_i (c3_i e-hat_i + c4_i s_j), one speaker per wave; they
-            //         are completed with dc_j / M in finalize, so sweep 3 never needs the e-hat images
+            // -- (d0) per-speaker rows KJP_j = (sum_i c4'_i) c-hat_j, one speaker per wave; completed with dc_j / M in
+            //         finalize (the e-hat part of the leave-one-out row is in gC_j already, through G's own column)
             if (want_grad && wid < nspk) {
                 const int jl = wid, j = j0 + jl;
-                float4 acc = zero4();
                 float bsum = 0.f;
-                for (int i = 0; i < M; ++i) {
-                    const int rl = jl * M + i;
-                    const float c3 = RS[rl * 8 + 4] * kSplitInv;
-                    bsum += RS[rl * 8 + 5];
-                    if (dact) {
-                        const float4 e = get_join4(ETh, ETl, rl * PH + d4);
-                        acc.x += c3 * e.x; acc.y += c3 * e.y; acc.z += c3 * e.z; acc.w += c3 * e.w;
-                    }
-                }
+                for (int i = 0; i < M; ++i) bsum += RS[(jl * M + i) * 8 + 5];
                 float4 c = zero4();
                 if (dact) c = get_join4(CHh, CHl, j * PH + d4);
-                const float bs = bsum * CST[j * 4 + 2] * kSplitInv;
-                bstore4(rsW, vrow, offKP + (unsigned)j * ROWB,
-                        make_float4(acc.x + bs * c.x, acc.y + bs * c.y, acc.z + bs * c.z, acc.w + bs * c.w));
+                const float bs = bsum * kSplitInv;
+                bstore4(rsW, vrow, offKP + (unsigned)j * ROWB, make_float4(bs * c.x, bs * c.y, bs * c.z, bs * c.w));
             }
             // -- (d) gC[k][d] += sum_r G_off[r][k] ET[r][d]; wave: centroids 32 kh.., columns 64 sl.. ---
             if (slice_on && want_grad) gemm_tn_32x64(Gh, Gl, GP, 32 * kh, ETh, ETl, PH, 64 * sl, lane, gc);
@@ -599,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
             // -- (d) epilogue straight from the accumulators: a 4 x 4 in-quad transpose gives every lane
             //        four consecutive columns of ONE row, so the stores are 16 bytes wide (8 rows x 128 B
             //        per wave-instruction) with no LDS staging and no barrier after the GEMM:
-            //        dE = ra acc + c1e e + rc c-hat_j + KJ_j
+            //        dE = ra acc + c1e e + KJ_j   (the c2 s_j term rides in G's own-speaker column)
             if (slice_on) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -613,13 +606,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         quad_transpose4(x, lane);
                         const int col = 64 * sl + 32 * b + 4 * cq;
                         const float4 e = ev[g][b];
-                        const float4 cj = get_join4(CHh, CHl, j * PH + col);
                         const float4 kj = *reinterpret_cast<const float4*>(GCS + j * P + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
                         bstore4<GE2E_AUX_DE>(rsG, rv ? (unsigned)((4 * h + pq) * D + col) * 4u : OOB,
                                              (unsigned)(r0 + 32 * kh + 8 * g) * ROWB,
-                                make_float4(x[0] * rs.x + e.x * rs.y + cj.x * rs.z + kj.x, x[1] * rs.x + e.y * rs.y + cj.y * rs.z + kj.y,
-                                            x[2] * rs.x + e.z * rs.y + cj.z * rs.z + kj.z, x[3] * rs.x + e.w * rs.y + cj.w * rs.z + kj.w));
+                                make_float4(x[0] * rs.x + e.x * rs.y + kj.x, x[1] * rs.x + e.y * rs.y + kj.y,
+                                            x[2] * rs.x + e.z * rs.y + kj.z, x[3] * rs.x + e.w * rs.y + kj.w));
                     }
                 }
             }
