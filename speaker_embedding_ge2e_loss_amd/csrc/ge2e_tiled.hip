@@ -292,11 +292,14 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     ss = wave_sum(ss);
     float rn, kap;
     unit_stats(sq, p.eps_cos, rn, kap);
+    float4 chv[NPC];            // c-hat_j, this lane's columns (the rows' own-speaker cosine xo below)
 #pragma unroll
     for (int c = 0; c < NPC; ++c) {
         const int d = 256 * c + 4 * lane;
+        chv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < npass && d < D) {
             const float4 ch = make_float4(s[c].x / fM * rn, s[c].y / fM * rn, s[c].z / fM * rn, s[c].w / fM * rn);
+            chv[c] = ch;
             *reinterpret_cast<float4*>(CHf + (size_t)j * D + d) = ch;
             h4 hi, lo;
             split4(scale4(ch, kSplitScale), hi, lo);
@@ -307,10 +310,11 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
     if (lane == 0) *reinterpret_cast<float4*>(CST) = make_float4(rn, kap, fM / rn, ss);
     // rows: 1/|e| and the e-hat images
     auto row_out = [&](int i, const float4 (&v)[NPC]) {
-        float ee = 0.f;
+        float red2[2] = {0.f, 0.f};      // |e|^2 and e . c-hat_j, reduced together
 #pragma unroll
-        for (int c = 0; c < NPC; ++c) ee += dot4(v[c], v[c]);
-        ee = wave_sum(ee);
+        for (int c = 0; c < NPC; ++c) { red2[0] += dot4(v[c], v[c]); red2[1] += dot4(v[c], chv[c]); }
+        wave_sum_n<2>(red2);
+        const float ee = red2[0];
         float rne, ke;
         unit_stats_fast(ee, p.eps_cos, rne, ke);
         const size_t r = (size_t)j * M + i;
@@ -324,7 +328,9 @@ __global__ __launch_bounds__(256) void ge2e_tiled_prep(Problem p, TiledWs L) {
                 *reinterpret_cast<h4*>(EHl + r * D + d) = lo;
             }
         }
-        if (lane == 0) *reinterpret_cast<float4*>(RST + (size_t)i * 4) = make_float4(rne, ke, ee, 0.f);
+        // rne, kappa_e, |e|^2 and xo = e-hat . c-hat_j in exact fp32 (the fused similarity + row kernel takes the own-speaker
+        // cosine from here: in its tile the column sits in ONE lane of another wave)
+        if (lane == 0) *reinterpret_cast<float4*>(RST + (size_t)i * 4) = make_float4(rne, ke, ee, red2[1] * rne);
     };
     if (RM > 0) {
 #pragma unroll
@@ -405,6 +411,284 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
                         make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_simrows (N <= 256, i.e. one 256-slot tile holds a row's whole similarity vector): k_sim and k_rows16 in ONE kernel --
+// the fp32 similarity block never goes to memory (2 x N M npad 4 bytes per batch less: 1.3 GB per launch at config 4,
+// where every kernel of this pipeline runs at the HBM rate) and one launch fewer.
+// The contraction is taken with the SLOTS as the A operand (C layout: register = slot, lane = row), so a row's 256
+// similarities are 64 registers of TWO lanes (l, l + 32) of TWO waves (wa = 0, 1): the row reductions are in-lane loops,
+// one half swap and one exchange through LDS.  The dL/dS tile then goes through LDS (the GEMM's stages are free by
+// then) so that the GH planes are written as whole rows.
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledWs L) {
+    static_assert(C::TM == 256 && C::TN == 256, "one 256 x 256 tile per workgroup");
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
+    const int rt = (NM + C::TN - 1) / C::TN;
+    const int t = xcd_major_tile(blockIdx.x, gridDim.x);
+    const int rtile = t % rt, bi = t / rt;
+    const size_t NMp = (size_t)NM;
+    Opnd A, Bo;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D;
+    A.lo = A.hi + (size_t)N * D;
+    A.ld = D; A.valid = min(C::TM, N);
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * C::TN * D;
+    Bo.lo = Bo.hi + NMp * D;
+    Bo.ld = D; Bo.valid = min(C::TN, NM - rtile * C::TN);
+    f32x16 acc[C::A2][C::B2];
+    gemm_zero<C>(acc);
+    gemm_tile<C, true, true>(A, Bo, D, gsm, tid, acc);      // ends with a barrier: the stages are free
+
+    // acc[a2][b2][v] = 2^16 X[slot][row], slot = 128 wa + 32 a2 + 8 (v >> 2) + 4 h + (v & 3), row = 64 wb + 32 b2 + l31
+    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN;
+    float* const XCH = reinterpret_cast<float*>(gsm);                 // [2 (wa)][256 rows][2] exchange of row partials
+    _Float16* const TT = gsm + 4096;                                   // [256 rows][TTP] halfs: one G plane at a time
+    constexpr int TTP = 256 + 4;
+    const float w = p.w ? *p.w : p.w_imm, bias = p.b ? *p.b : p.b_imm;
+    const float eps = p.eps, log_eps = p.log_eps;
+    const float inv_m1 = 1.0f / (float)(M - 1);
+    const int soff = 128 * wa + 4 * h;                                 // slot of (a2 = 0, v = 0)
+
+    float rne[2], ke[2], cosd[2], sjj[2], rnu[2], ku[2], xo[2], csx[2], csy[2], csz[2];
+    int jl[2];          // own-speaker slot relative to soff (matches 32 a2 + 8 (v >> 2) + (v & 3) of at most one register)
+    bool rv[2];
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        const int rloc = 64 * wb + 32 * b2 + l31;
+        const int r = rtile * C::TN + rloc;
+        rv[b2] = r < NM;
+        const int rc = rv[b2] ? r : NM - 1;
+        const int j = rc / M;
+        const float4 rst = *reinterpret_cast<const float4*>(p.ws + L.rst + ((size_t)bi * NM + rc) * 4);   // rne ke ee xo
+        const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);       // rn kap |s| |s|^2
+        rne[b2] = rst.x; ke[b2] = rst.y; xo[b2] = rst.w;
+        csx[b2] = cs.x; csy[b2] = cs.y; csz[b2] = cs.z;
+        const float ee = rst.z;
+        const float es = rst.w * cs.z / rst.x;
+        const float eu = (es - ee) * inv_m1;
+        const float uu = fmaxf((cs.w - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+        unit_stats_fast(uu, p.eps_cos, rnu[b2], ku[b2]);
+        cosd[b2] = eu * rst.x * rnu[b2];
+        sjj[b2] = w * (cosd[b2] + eps) + bias;
+        jl[b2] = j - soff;
+    }
+    const int nl = N - soff;        // slots of this lane with (32 a2 + 8 (v >> 2) + (v & 3)) < nl exist
+    const float ws = w * kSplitInv2, bs = w * eps + bias;       // S = ws acc + bs
+
+    // ---- row maximum over the other speakers' columns (the own column enters with its leave-one-out value) ----------
+    // (jl and nl are re-read through an opaque copy in every phase: compared once, hipcc keeps all 128 (exists, own-column)
+    // lane masks of the three loops below in SGPRs -- 250 spilled scalars)
+#define GE2E_SR_OPAQUE() int jq[2] = {jl[0], jl[1]}, nq = nl; asm volatile("" : "+v"(jq[0]), "+v"(jq[1]), "+v"(nq))
+    float best[2]; int besti[2];
+    float mx[2];
+    {
+    GE2E_SR_OPAQUE();
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        float m = -INFINITY;
+        best[b2] = -INFINITY; besti[b2] = 0x7fffffff;
+        if (p.variant == 0) {       // (the two variants as separate straight-line loops: no per-element control flow)
+#pragma unroll
+            for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
+                    const float sv = fmaf(ws, acc[a2][b2][v], bs);
+                    m = (c < nq && c != jq[b2]) ? fmaxf(m, sv) : m;
+                }
+        } else {
+            float bv = -INFINITY; int bi_ = 0x7fffffff;
+#pragma unroll
+            for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);     // ascending slot order: ties keep the lower slot
+                    const float sv = fmaf(ws, acc[a2][b2][v], bs);
+                    const bool better = c < nq && c != jq[b2] && sv > bv;
+                    bv = better ? sv : bv;
+                    bi_ = better ? soff + c : bi_;
+                }
+            best[b2] = bv; besti[b2] = bi_;
+        }
+        {   // the two half-rows of the wave
+            auto sw = GE2E_SWAP32(__float_as_uint(m));
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        mx[b2] = m;
+    }
+    }
+    if (p.variant == 1) {
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2) {
+            auto a = GE2E_SWAP32(__float_as_uint(best[b2]));
+            auto b = GE2E_SWAP32((unsigned)besti[b2]);
+            float v0 = __uint_as_float(a[0]); int i0 = (int)b[0];
+            argmax_merge(v0, i0, __uint_as_float(a[1]), (int)b[1]);
+            best[b2] = v0; besti[b2] = i0;
+        }
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2) {
+            const int rloc = 64 * wb + 32 * b2 + l31;
+            XCH[(wa * 256 + rloc) * 2] = p.variant == 1 ? best[b2] : mx[b2];
+            XCH[(wa * 256 + rloc) * 2 + 1] = __int_as_float(besti[b2]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        const int rloc = 64 * wb + 32 * b2 + l31;
+        const float om = XCH[((wa ^ 1) * 256 + rloc) * 2];
+        if (p.variant == 1) {
+            const int oi = __float_as_int(XCH[((wa ^ 1) * 256 + rloc) * 2 + 1]);
+            argmax_merge(best[b2], besti[b2], om, oi);
+        } else {
+            mx[b2] = fmaxf(fmaxf(fmaxf(mx[b2], om), sjj[b2]), log_eps);
+        }
+    }
+    __syncthreads();
+
+    // ---- exponentials, row sums -> dL/dS in place of the similarities ----------------------------------------------
+    float zl[2], al[2];
+    {
+    GE2E_SR_OPAQUE();
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        float z = 0.f, a = 0.f;
+        if (p.variant == 0) {
+            const float tb = bs - mx[b2];
+#pragma unroll
+            for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
+                    const float x = acc[a2][b2][v];
+                    float g = __expf(fmaf(ws, x, tb));
+                    g = (c < nq && c != jq[b2]) ? g : 0.f;
+                    z += g;
+                    a = fmaf(g, x, a);
+                    acc[a2][b2][v] = g;
+                }
+        } else {
+#pragma unroll
+            for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
+                    const bool hit = soff + c == besti[b2] && c < nq && c != jq[b2];
+                    a = hit ? acc[a2][b2][v] : a;          // the raw similarity of the best other speaker
+                    acc[a2][b2][v] = hit ? 1.0f : 0.f;
+                }
+        }
+        {
+            auto s0 = GE2E_SWAP32(__float_as_uint(z));
+            z = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
+            auto s1 = GE2E_SWAP32(__float_as_uint(a));
+            a = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+        }
+        zl[b2] = z; al[b2] = a;
+    }
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2) {
+            const int rloc = 64 * wb + 32 * b2 + l31;
+            XCH[(wa * 256 + rloc) * 2] = zl[b2];
+            XCH[(wa * 256 + rloc) * 2 + 1] = al[b2];
+        }
+    }
+    __syncthreads();
+    float gs[2], og[2];     // scale of the other columns' values, value of the own column (both x 2^8)
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        const int rloc = 64 * wb + 32 * b2 + l31;
+        // fixed order (wa = 0 first): both waves of a row form the same sums
+        const float z0 = wa == 0 ? zl[b2] : XCH[rloc * 2], z1 = wa == 1 ? zl[b2] : XCH[(256 + rloc) * 2];
+        const float a0 = wa == 0 ? al[b2] : XCH[rloc * 2 + 1], a1 = wa == 1 ? al[b2] : XCH[(256 + rloc) * 2 + 1];
+        const float zp = z0 + z1, ap = (a0 + a1) * kSplitInv2;
+        float per, ad0, coefsum, db_row, gsc;
+        if (p.variant == 0) {
+            const float zoff = zp + __expf(log_eps - mx[b2]);
+            const float z = zoff + __expf(sjj[b2] - mx[b2]);
+            per = (mx[b2] - sjj[b2]) + __logf(z);
+            const float rz = 1.0f / z;
+            ad0 = -zoff * rz;                         // dL/dS on the own-speaker column: -(1 - p_jj) = -z_off / z
+            coefsum = fmaf(ap, rz, ad0 * cosd[b2]);   // sum_k dL/dS_k c0_k
+            db_row = fmaf(zp, rz, ad0);
+            gsc = rz;
+        } else {
+            const float pos = 1.0f / (1.0f + __expf(-sjj[b2]));
+            const float neg = (N > 1) ? 1.0f / (1.0f + __expf(-best[b2])) : 0.0f;
+            per = 1.0f - pos + neg;
+            ad0 = -pos * (1.0f - pos);
+            const float gn = neg * (1.0f - neg);
+            coefsum = fmaf(gn, ap, ad0 * cosd[b2]);   // (a0 + a1) is the raw similarity of the best other speaker
+            db_row = gn + ad0;
+            gsc = gn;
+        }
+        if (!rv[b2]) { ad0 = 0.f; gsc = 0.f; }
+        const float rho = rnu[b2] * inv_m1, t1 = ku[b2] * cosd[b2] * rho;
+        // the own-speaker column carries o = c2 |s_j| / (ra w)  (k_rows16 above)
+        og[b2] = rho * (rne[b2] + t1) * csz[b2] / rne[b2] * ad0 * kSplitScale;
+        gs[b2] = gsc * kSplitScale;
+        if (wa == 0 && h == 0 && rv[b2]) {
+            const size_t gr = (size_t)bi * NM + rtile * C::TN + rloc;
+            const float coef = w * coefsum, ad = w * ad0;
+            const float c2 = rho * (ad * rne[b2] + ad * ku[b2] * cosd[b2] * rnu[b2] * inv_m1);
+            const float c1 = (-ke[b2] * coef * rne[b2] - ad * rnu[b2] * inv_m1) - c2 / rne[b2];
+            const float alpha = ad * rnu[b2] * (1.0f + ku[b2] * cosd[b2] * rho / rne[b2]);
+            const float beta = -ad * rnu[b2] * ku[b2] * cosd[b2] * rho;
+            float* rs = p.ws + L.rs + gr * 8;
+            *reinterpret_cast<float4*>(rs) = make_float4(rne[b2] * (w * kSplitInv2), c1 * rne[b2], 0.f, 0.f);
+            *reinterpret_cast<float4*>(rs + 4) = make_float4(inv_m1 * (beta * csz[b2] + csy[b2] * alpha * xo[b2]), per,
+                                                              fmaf(eps, db_row, coefsum), db_row);
+            if (p.per) p.per[gr] = per;
+        }
+    }
+    __syncthreads();        // XCH has been read: the region below it is about to hold the G tile
+
+    // ---- dL/dS -> split fp16 -> LDS tile [row][slot] -> the GH planes as whole rows, one plane at a time ------------
+    _Float16* const GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NMp * npad + (size_t)rtile * C::TN * npad;
+    const int rows_here = min(C::TN, NM - rtile * C::TN);
+#pragma unroll 1
+    for (int plane = 0; plane < 2; ++plane) {
+        GE2E_SR_OPAQUE();
+        (void)nq;
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2) {
+            const int rloc = 64 * wb + 32 * b2 + l31;
+#pragma unroll
+            for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+                for (int vg = 0; vg < 4; ++vg) {
+                    float gv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 32 * a2 + 8 * vg + e;
+                        gv[e] = c == jq[b2] ? og[b2] : acc[a2][b2][4 * vg + e] * gs[b2];
+                    }
+                    h4 hi, lo;
+                    split4(make_float4(gv[0], gv[1], gv[2], gv[3]), hi, lo);
+                    *reinterpret_cast<h4*>(TT + rloc * TTP + soff + 32 * a2 + 8 * vg) = plane == 0 ? hi : lo;
+                }
+        }
+        __syncthreads();
+        _Float16* const G = GHh + (size_t)plane * NMp * npad;
+        for (int idx = tid; idx < 256 * 32; idx += C::NT) {          // 32 16-byte pieces per row
+            const int row = idx >> 5, c8 = (idx & 31) * 8;
+            if (row < rows_here && c8 < npad) {
+                const uint2 lo8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8);
+                const uint2 hi8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8 + 4);
+                *reinterpret_cast<uint4*>(G + (size_t)row * npad + c8) = make_uint4(lo8.x, lo8.y, hi8.x, hi8.y);
+            }
+        }
+        __syncthreads();
+    }
+#undef GE2E_SR_OPAQUE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -895,7 +1179,7 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
         const void* small[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), reinterpret_cast<const void*>(ge2e_tiled_gc<C1>),
                                reinterpret_cast<const void*>(ge2e_tiled_ge<C1>)};
         const void* big[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), reinterpret_cast<const void*>(ge2e_tiled_gc<C2>),
-                             reinterpret_cast<const void*>(ge2e_tiled_ge<C2>)};
+                             reinterpret_cast<const void*>(ge2e_tiled_ge<C2>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2>)};
         for (const void* fn : small) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1::LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -912,12 +1196,17 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= fill;
     const bool big_gc = p.N >= 256 && p.D >= 256 && (unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) >= fill;
     const bool big_ge = NM >= 256 && p.D >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256) >= fill;
+    // one 256-slot tile holds a whole similarity row: similarity contraction + row pass in one kernel (config 4)
+    const bool fused_rows = L.npad <= 256 && p.N > 128 && NM >= 256 && (unsigned)p.B * tiles(NM, 256) >= fill;
     launch_prep(p, L, stream);
-    if (big_sim)
+    if (fused_rows)
+        hipLaunchKernelGGL(ge2e_tiled_simrows<C2>, dim3((unsigned)p.B * tiles(NM, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
-    if (L.npad <= 256)
+    if (fused_rows) {
+    } else if (L.npad <= 256)
         hipLaunchKernelGGL(ge2e_tiled_rows16, dim3((unsigned)(((size_t)p.B * NM + 15) / 16)), dim3(256), 0, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);

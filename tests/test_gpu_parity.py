@@ -386,3 +386,22 @@ def test_cos_sim_on_the_matrix_cores(GF, shape):
         t = torch.as_tensor(E[bi])
         ref = orc.expand_form_cos_sim(t, orc.centroids(t)).numpy()
         assert np.abs(cos[bi].cpu().numpy() - ref).max() < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 10, 256), (2, 200, 4, 64), (2, 129, 7, 128), (1, 256, 2, 64), (2, 255, 3, 192)])
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_tiled_fused_similarity_and_row_pass(GF, shape, variant):
+    """129 <= N <= 256 (one 256-slot tile holds a similarity row): TILED runs the similarity contraction and the row pass
+    as ONE kernel (ge2e_tiled_simrows).  Uneven N (pad slots), row tiles that end inside a batch, both variants."""
+    B, N, M, D = shape
+    E = orc.synth_embeddings(shape, "raw", seed=N + M)
+    ref = orc.closed_form(E, 7.5, -2.0, variant=variant)
+    check(run_hip(GF, E, 7.5, -2.0, variant, "tiled"), ref, "tiled", f"{shape}/{variant}")
+    # forward only (dE = NULL) through the same kernel
+    dev = torch.device("cuda:0")
+    e = torch.as_tensor(E, device=dev)
+    o = GF.loss_fwd_bwd(e, torch.tensor(7.5, device=dev), torch.tensor(-2.0, device=dev), variant=variant, impl="tiled",
+                        need_grad=False, need_per=True)
+    torch.cuda.synchronize()
+    assert np.allclose(o.loss.cpu().numpy(), ref["loss"], rtol=2e-5)
+    assert np.allclose(o.per.cpu().numpy(), ref["per"], rtol=2e-4, atol=2e-5)
