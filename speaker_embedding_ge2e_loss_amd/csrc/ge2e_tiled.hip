@@ -421,7 +421,9 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
 // similarities are 64 registers of TWO lanes (l, l + 32) of TWO waves (wa = 0, 1): the row reductions are in-lane loops,
 // one half swap and one exchange through LDS.  The dL/dS tile then goes through LDS (the GEMM's stages are free by
 // then) so that the GH planes are written as whole rows.
-template <class C>
+// CONTRAST / FULL (N == 256: every slot of the tile exists) are compile-time: the three passes over the 128 accumulators of a
+// lane are the kernel's vector work, and every per-element test in them is two instructions.
+template <class C, bool CONTRAST, bool FULL>
 __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledWs L) {
     static_assert(C::TM == 256 && C::TN == 256, "one 256 x 256 tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];
@@ -490,14 +492,14 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
     for (int b2 = 0; b2 < C::B2; ++b2) {
         float m = -INFINITY;
         best[b2] = -INFINITY; besti[b2] = 0x7fffffff;
-        if (p.variant == 0) {       // (the two variants as separate straight-line loops: no per-element control flow)
+        if (!CONTRAST) {       // (the two variants as separate straight-line loops: no per-element control flow)
 #pragma unroll
             for (int a2 = 0; a2 < C::A2; ++a2)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
                     const float sv = fmaf(ws, acc[a2][b2][v], bs);
-                    m = (c < nq && c != jq[b2]) ? fmaxf(m, sv) : m;
+                    m = ((FULL || c < nq) && c != jq[b2]) ? fmaxf(m, sv) : m;
                 }
         } else {
             float bv = -INFINITY; int bi_ = 0x7fffffff;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
                 for (int v = 0; v < 16; ++v) {
                     const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);     // ascending slot order: ties keep the lower slot
                     const float sv = fmaf(ws, acc[a2][b2][v], bs);
-                    const bool better = c < nq && c != jq[b2] && sv > bv;
+                    const bool better = (FULL || c < nq) && c != jq[b2] && sv > bv;
                     bv = better ? sv : bv;
                     bi_ = better ? soff + c : bi_;
                 }
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
         mx[b2] = m;
     }
     }
-    if (p.variant == 1) {
+    if (CONTRAST) {
 #pragma unroll
         for (int b2 = 0; b2 < C::B2; ++b2) {
             auto a = GE2E_SWAP32(__float_as_uint(best[b2]));
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
 #pragma unroll
         for (int b2 = 0; b2 < C::B2; ++b2) {
             const int rloc = 64 * wb + 32 * b2 + l31;
-            XCH[(wa * 256 + rloc) * 2] = p.variant == 1 ? best[b2] : mx[b2];
+            XCH[(wa * 256 + rloc) * 2] = CONTRAST ? best[b2] : mx[b2];
             XCH[(wa * 256 + rloc) * 2 + 1] = __int_as_float(besti[b2]);
         }
     }
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
     for (int b2 = 0; b2 < C::B2; ++b2) {
         const int rloc = 64 * wb + 32 * b2 + l31;
         const float om = XCH[((wa ^ 1) * 256 + rloc) * 2];
-        if (p.variant == 1) {
+        if (CONTRAST) {
             const int oi = __float_as_int(XCH[((wa ^ 1) * 256 + rloc) * 2 + 1]);
             argmax_merge(best[b2], besti[b2], om, oi);
         } else {
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
 #pragma unroll
     for (int b2 = 0; b2 < C::B2; ++b2) {
         float z = 0.f, a = 0.f;
-        if (p.variant == 0) {
+        if (!CONTRAST) {
             const float tb = bs - mx[b2];
 #pragma unroll
             for (int a2 = 0; a2 < C::A2; ++a2)
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
                     const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
                     const float x = acc[a2][b2][v];
                     float g = __expf(fmaf(ws, x, tb));
-                    g = (c < nq && c != jq[b2]) ? g : 0.f;
+                    g = ((FULL || c < nq) && c != jq[b2]) ? g : 0.f;
                     z += g;
                     a = fmaf(g, x, a);
                     acc[a2][b2][v] = g;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
-                    const bool hit = soff + c == besti[b2] && c < nq && c != jq[b2];
+                    const bool hit = soff + c == besti[b2] && (FULL || c < nq) && c != jq[b2];
                     a = hit ? acc[a2][b2][v] : a;          // the raw similarity of the best other speaker
                     acc[a2][b2][v] = hit ? 1.0f : 0.f;
                 }
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
         const float a0 = wa == 0 ? al[b2] : XCH[rloc * 2 + 1], a1 = wa == 1 ? al[b2] : XCH[(256 + rloc) * 2 + 1];
         const float zp = z0 + z1, ap = (a0 + a1) * kSplitInv2;
         float per, ad0, coefsum, db_row, gsc;
-        if (p.variant == 0) {
+        if (!CONTRAST) {
             const float zoff = zp + __expf(log_eps - mx[b2]);
             const float z = zoff + __expf(sjj[b2] - mx[b2]);
             per = (mx[b2] - sjj[b2]) + __logf(z);
@@ -1179,7 +1181,9 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
         const void* small[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), reinterpret_cast<const void*>(ge2e_tiled_gc<C1>),
                                reinterpret_cast<const void*>(ge2e_tiled_ge<C1>)};
         const void* big[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), reinterpret_cast<const void*>(ge2e_tiled_gc<C2>),
-                             reinterpret_cast<const void*>(ge2e_tiled_ge<C2>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2>)};
+                             reinterpret_cast<const void*>(ge2e_tiled_ge<C2>),
+                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, false, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, false, true>),
+                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, true, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, true, true>)};
         for (const void* fn : small) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1::LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -1199,9 +1203,16 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     // one 256-slot tile holds a whole similarity row: similarity contraction + row pass in one kernel (config 4)
     const bool fused_rows = L.npad <= 256 && p.N > 128 && NM >= 256 && (unsigned)p.B * tiles(NM, 256) >= fill;
     launch_prep(p, L, stream);
-    if (fused_rows)
-        hipLaunchKernelGGL(ge2e_tiled_simrows<C2>, dim3((unsigned)p.B * tiles(NM, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
-    else if (big_sim)
+    if (fused_rows) {
+        const dim3 g((unsigned)p.B * tiles(NM, 256));
+        if (p.variant == 1) {
+            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C2, true, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            else hipLaunchKernelGGL((ge2e_tiled_simrows<C2, true, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        } else {
+            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C2, false, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            else hipLaunchKernelGGL((ge2e_tiled_simrows<C2, false, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        }
+    } else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
