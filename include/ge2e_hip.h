@@ -79,6 +79,14 @@ int ge2e_resolve_impl(int B, int N, int M, int D, int variant, int impl);
 /* Bytes of scratch ge2e_loss_fwd_bwd / ge2e_cos_sim need for this shape. */
 size_t ge2e_workspace_bytes(int B, int N, int M, int D, int variant, int impl);
 
+/* OPTIONAL, once per workspace allocation (enqueue-only, one 2-us launch): writes the clean control block GE2E_IMPL_TEAM
+ * expects at the head of its workspace.  The block is self-cleaning -- every call hands it back the way it found it, so
+ * the steady state has no zeroing launch in front of the kernel -- and a workspace that was NOT initialised (or that another
+ * implementation has used in between) is still safe: the first call on it is computed by the in-call fall-back launch,
+ * which leaves a clean block behind.  Calling this just makes the first call already run the team kernel.  Workspaces
+ * smaller than the block (26 KB, the first bytes of every loss workspace whichever implementation runs) are left alone.  (The reference has no counterpart: s3's module allocates nothing.) */
+int ge2e_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+
 /*
  * GE2ELoss.forward + its autograd backward in one call (s3:19-30 + s4:200).
  *   loss          [B]        sum over the (N,M) per-utterance losses (s3:126)

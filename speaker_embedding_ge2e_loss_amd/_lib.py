@@ -29,6 +29,7 @@ PROTOTYPES = {
     "ge2e_strerror": (C.c_char_p, [C.c_int]),
     "ge2e_resolve_impl": (C.c_int, [C.c_int] * 6),
     "ge2e_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "ge2e_workspace_init": (C.c_int, [_fp, C.c_size_t, _fp]),
     "ge2e_loss_fwd_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float,
                                     C.c_float, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp,
                                     C.c_size_t, _fp]),

@@ -58,16 +58,22 @@ int resolve(int B, int N, int M, int D, int variant, int impl) {
     }
 }
 
+// The first team_head_bytes() of EVERY loss workspace are the team kernel's control block (ge2e_team.hpp), whichever
+// implementation runs: the others put their scratch behind it.  A workspace that callers reuse across shapes and
+// implementations (the Python module path caches one per stream) therefore keeps a clean block, and a team call is never
+// pushed onto its fall-back -- with that kernel's last-bit-different results -- by what ran on the workspace before.
 size_t ws_bytes(int B, int N, int M, int D, int impl) {
+    size_t own = 0;
     switch (impl) {
-        case GE2E_IMPL_GENERIC: return generic_workspace_bytes(B, N, M, D);
-        case GE2E_IMPL_FUSED_F32: return fused_f32_workspace_bytes(B, N, M, D);
-        case GE2E_IMPL_FUSED_SPLIT: return fused_split_workspace_bytes(B, N, M, D);
-        case GE2E_IMPL_TILED: return tiled_workspace_bytes(B, N, M, D);
-        case GE2E_IMPL_TEAM: return team_workspace_bytes(B, N, M, D);
+        case GE2E_IMPL_GENERIC: own = generic_workspace_bytes(B, N, M, D); break;
+        case GE2E_IMPL_FUSED_F32: own = fused_f32_workspace_bytes(B, N, M, D); break;
+        case GE2E_IMPL_FUSED_SPLIT: own = fused_split_workspace_bytes(B, N, M, D); break;
+        case GE2E_IMPL_TILED: own = tiled_workspace_bytes(B, N, M, D); break;
+        case GE2E_IMPL_TEAM: return team_workspace_bytes(B, N, M, D);      // its layout starts with the block
         case GE2E_IMPL_WAVE: return 0;
         default: return 0;
     }
+    return own > 0 ? own + team_head_bytes() : 0;
 }
 
 int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* stream) {
@@ -78,7 +84,7 @@ int run(Problem& p, int impl, void* workspace, size_t workspace_bytes, void* str
     const size_t need = ws_bytes(p.B, p.N, p.M, p.D, chosen);
     if (need > 0 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))) return GE2E_ERR_WORKSPACE;
     if (((uintptr_t)p.E & 15) || ((uintptr_t)p.dE & 15)) return GE2E_ERR_ALIGN;
-    p.ws = (float*)workspace;
+    p.ws = (float*)((char*)workspace + (need > 0 && chosen != GE2E_IMPL_TEAM ? team_head_bytes() : 0));
 #ifdef GE2E_PROFILE
     p.prof = g_prof;
 #endif
@@ -131,6 +137,12 @@ size_t ge2e_workspace_bytes(int B, int N, int M, int D, int variant, int impl) {
     return chosen < 0 ? 0 : ws_bytes(B, N, M, D, chosen);
 }
 
+int ge2e_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace) return GE2E_ERR_NULL;
+    if (workspace_bytes < team_head_bytes()) return GE2E_OK;      // too small for any team launch: nothing to prepare
+    return (int)launch_team_head_init(workspace, team_head_bytes(), false, (hipStream_t)stream);   // > 0: a hipError_t, like every launch
+}
+
 int ge2e_loss_fwd_bwd(const float* E, int B, int N, int M, int D, const float* w, const float* b,
                       float eps_cos, float eps, int variant, int impl, float* loss,
                       float* per_emb_loss, float* dE, float* dw, float* db, void* workspace,
@@ -172,7 +184,7 @@ static bool cos_on_mfma(int N, int M, int D) { return N >= 16 && tiled_supports(
 
 size_t ge2e_cos_sim_workspace_bytes(int B, int N, int M, int D) {
     if (!shape_ok(B, N, M, D)) return 0;
-    const size_t g = generic_workspace_bytes(B, N, M, D);
+    const size_t g = ws_bytes(B, N, M, D, GE2E_IMPL_GENERIC);      // what run() asks for (the control block's room included)
     const size_t t = cos_on_mfma(N, M, D) ? tiled_workspace_bytes(B, N, M, D) : 0;
     return g > t ? g : t;
 }

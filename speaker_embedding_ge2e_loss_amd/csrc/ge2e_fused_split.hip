@@ -30,6 +30,7 @@
 #include "ge2e_common.hpp"
 #include "ge2e_fused.hpp"
 #include "ge2e_split_gemm.hpp"
+#include "ge2e_team.hpp"   // team_head_cleanup: the gated fall-back launch hands the team control block back clean
 
 namespace ge2e {
 
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const bool slice_on = 64 * sl < D;
 
     // fall-back launch behind the team kernel (ge2e_team.hip): nothing to do unless its abort word is up
-    if (p.gate && __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (p.gate && __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        team_head_cleanup(p.cleanup_head, p.cleanup_n16);     // the steady state: nothing to redo, the block is handed back clean
+        return;
+    }
     const int spt = wsl.spt;          // speakers per tile
     const int ntiles = wsl.ntiles;
     const unsigned ws_bytes = (unsigned)(wsl.stride * sizeof(float));
@@ -624,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         have_sums = has_next;
     }
     GE2E_PROF_FLUSH(10)
+    if (p.gate) team_head_cleanup(p.cleanup_head, p.cleanup_n16);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -185,7 +185,7 @@ size_t selftest_team_bytes(int payload) {
 hipError_t launch_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds, int payload, unsigned* out,
                                 hipStream_t stream) {
     if (grid < 1 || grid > 64 * TEAM || ws_bytes < selftest_team_bytes(payload)) return hipErrorInvalidValue;
-    hipError_t err = hipMemsetAsync(ws, 0, sizeof(TeamCtl) + 64 * sizeof(TeamFlags), stream);
+    hipError_t err = launch_team_head_init(ws, (sizeof(TeamCtl) + 64 * sizeof(TeamFlags) + 15) / 16 * 16, false, stream);
     if (err != hipSuccess) return err;
     err = hipMemsetAsync(out, 0, 16 * sizeof(unsigned), stream);
     if (err != hipSuccess) return err;

@@ -220,7 +220,8 @@ TeamKWs team_layout(int N, int M, int D) {
     L.spm = (N + TEAM - 1) / TEAM;
     L.rt = (L.spm * M + 15) / 16 * 16;
     L.mul_m = (65536 + M - 1) / M;
-    L.head_bytes = (unsigned)align_up(sizeof(TeamCtl) + 64 * sizeof(TeamKFlags), 256);
+    L.head_bytes = (unsigned)team_head_bytes();
+    static_assert(sizeof(TeamKFlags) == 3 * 128 && team_head_bytes() >= sizeof(TeamCtl) + 64 * sizeof(TeamKFlags), "head layout");
     const size_t et = (size_t)2 * L.rt * D * 2;
     const size_t xb = team_xb_bytes(L.rt, D);
     const size_t g = team_g_bytes(L.rt, D);
@@ -1061,14 +1062,21 @@ _Pragma("unroll")                                                               
 }
 
 // ---------------------------------------------------------------------------------------------
-// zeroes the control block at the head of the workspace (n16 16-byte pieces); one_word >= 0: that 32-bit word becomes 1
-__global__ __launch_bounds__(256) void team_zero_head(uint4* head, int n16, int one_word) {
+// a clean control block (zeros + magic) at the head of a workspace: n16 16-byte pieces; raise_abort: the abort word comes up 1
+__global__ __launch_bounds__(256) void team_zero_head(uint4* head, int n16, int raise_abort) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n16) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (one_word >= 0 && (one_word >> 2) == i) (&v.x)[one_word & 3] = 1u;
+        if (i == (int)(offsetof(TeamCtl, magic) / 16)) v.x = TEAM_MAGIC;
+        if (raise_abort && i == (int)(offsetof(TeamCtl, abort_) / 16)) v.x = 1u;
         head[i] = v;
     }
+}
+hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hipStream_t stream) {
+    const int n16 = (int)(bytes / 16);
+    hipLaunchKernelGGL(team_zero_head, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<uint4*>(head), n16,
+                       raise_abort ? 1 : 0);
+    return hipGetLastError();
 }
 
 template <int NCH, int MR, int RBT, bool CONTRAST, bool FWD = false>
@@ -1078,15 +1086,13 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, (unsigned)L.lds_bytes, &nb);
     if (err != hipSuccess) return err;
-    // The control block is zeroed by a kernel of ours, not by hipMemsetAsync: captured in a HIP graph next to other fill /
-    // memset nodes (a module step under torch.cuda.graph), the memset node replayed with another node's pattern from the
-    // second replay on -- the block came up as 0x43C00000 everywhere, every team saw "already aborted" and the fall-back
-    // redid each call (tools/graph_module_step.py).  (p.test_abort: diagnostics, the abort word raised in front of the launch.)
-    hipLaunchKernelGGL(team_zero_head, dim3((L.head_bytes / 16 + 255) / 256), dim3(256), 0, stream,
-                       reinterpret_cast<uint4*>(p.ws), (int)(L.head_bytes / 16),
-                       p.test_abort ? (int)(offsetof(TeamCtl, abort_) / 4) : -1);
-    err = hipGetLastError();
-    if (err != hipSuccess) return err;
+    // No zeroing launch: the control block is self-cleaning (ge2e_team.hpp) -- the previous call's gated launch left it
+    // clean, ge2e_workspace_init wrote a first clean one, and anything else makes this launch fall back and be cleaned
+    // up after.  (p.test_abort: diagnostics, a block with the abort word raised is written in front of the launch.)
+    if (p.test_abort) {
+        err = launch_team_head_init(p.ws, L.head_bytes, true, stream);
+        if (err != hipSuccess) return err;
+    }
     // Every workgroup must be resident (they wait for each other): grid <= resident capacity is what a cooperative
     // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
     // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
@@ -1132,6 +1138,8 @@ hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem f = p_in;
     const TeamCtl* ctl = reinterpret_cast<const TeamCtl*>(p_in.ws);
     f.gate = &ctl->abort_;
+    f.cleanup_head = reinterpret_cast<unsigned*>(p_in.ws);     // its last workgroup hands the control block back clean
+    f.cleanup_n16 = (int)(L.head_bytes / 16);
     f.grid_cap = team_fallback_grid(p.B);
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
                                     align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange(p.D).stride, 256));

@@ -17,6 +17,7 @@
 #pragma once
 #include "ge2e_common.hpp"
 #include "ge2e_split_gemm.hpp"
+#include <cstddef>
 
 namespace ge2e {
 
@@ -29,15 +30,48 @@ constexpr int MAX_XCD = 8;
 constexpr unsigned long long TEAM_FORM_TICKS = 200000ull;      // 2 ms: every workgroup of the grid has started
 constexpr unsigned long long TEAM_HANDOFF_TICKS = 400000ull;   // 4 ms: a hand-off inside a running team
 
-// Control block at the head of the workspace; zeroed by the team_zero_head kernel in front of every launch (not a memset
-// node: captured in a HIP graph beside torch's fill nodes, a memset node replayed with another node's pattern).
-// Each word that is polled or bumped sits on its own 128-byte line.
+// Control block at the head of the workspace.  SELF-CLEANING (round 4): a call leaves it the way it found it -- all zeros
+// plus the magic word -- so the steady state has no zeroing launch in front of the team kernel:
+//   * the LAST workgroup of the gated fall-back launch behind the team kernel (every call has one) re-zeroes the block
+//     and sets `magic` again (`done` counts its workgroups; by then every one of them has read the gate);
+//   * a block that does not carry the magic -- a fresh allocation, memory another implementation has written over -- makes
+//     every workgroup raise the abort word instead of forming teams: the fall-back computes that call and its clean-up
+//     leaves a valid block behind.  ge2e_workspace_init() (include/ge2e_hip.h) writes a valid block explicitly, so that
+//     a new workspace's first call already runs the team kernel; the Python side does that in alloc_workspace.
+// (Zeroed by a kernel, not a memset node: captured in a HIP graph beside torch's fill nodes, a memset node replayed with
+// another node's pattern.)  Each word that is polled or bumped sits on its own 128-byte line.
+constexpr unsigned TEAM_MAGIC = 0x6E2E7EA3u;
 struct TeamCtl {
     unsigned arrived;   unsigned pad0[31];
     unsigned abort_;    unsigned pad1[31];
     unsigned nct;       unsigned pad2[31];              // complete teams (written by workgroup 0, diagnostic)
     unsigned xcd_count[MAX_XCD][32];                    // one line per XCD
+    unsigned done;      unsigned pad3[31];              // workgroups of the gated fall-back launch that have finished
+    unsigned magic;     unsigned pad4[31];              // TEAM_MAGIC <=> the rest of the block (and the team flags) is zero
+    unsigned fallbacks; unsigned pad5[31];              // diagnostic, survives the clean-up: calls on this workspace whose abort
+                                                        // word was up (no team formed, a hand-off timed out, unclean block)
 };
+// bytes of the control block + 64 per-team flag records (shape-independent; TeamKFlags = 3 lines, TeamFlags = 2)
+constexpr size_t team_head_bytes() { return (sizeof(TeamCtl) + 64 * 3 * 128 + 255) / 256 * 256; }
+// zero `bytes` at `head` (a multiple of 16) and set the magic (and, for diagnostics, the abort word): one small launch
+hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hipStream_t stream);
+// Clean-up half of the protocol, called by ALL threads of EVERY workgroup of the gated launch right before they leave (also
+// when the gate was down): the last workgroup restores the clean block.
+__device__ __forceinline__ void team_head_cleanup(unsigned* head, int n16) {
+    if (head == nullptr || threadIdx.x >= 64) return;
+    TeamCtl* ctl = reinterpret_cast<TeamCtl*>(head);
+    int last = 0;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
+    // (the team kernel and every other workgroup of this launch are done with the block: plain accesses)
+    const bool was_clean = ctl->magic == TEAM_MAGIC;
+    const unsigned fb = (was_clean ? ctl->fallbacks : 0u) + (ctl->abort_ != 0u ? 1u : 0u);
+    uint4* h16 = reinterpret_cast<uint4*>(head);
+    for (int i = threadIdx.x; i < n16; i += 64)
+        h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fb : 0u), 0u, 0u, 0u);
+}
 struct TeamFlags {                                      // per team
     unsigned c1;        unsigned pad0[31];              // hand-off 1 (unit centroids published)
     unsigned c2;        unsigned pad1[31];              // hand-off 2 (partial centroid gradients published)
@@ -79,7 +113,14 @@ __device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, T
 
 // Called by all threads of the workgroup; `sh` is 4 ints of LDS.  Contains workgroup barriers.
 __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
-    if (threadIdx.x == 0 && ld_poll(&ctl->abort_)) {   // launch already marked as failed (diagnostics): nobody forms a team
+    if (threadIdx.x == 0 && ld_poll(&ctl->magic) != TEAM_MAGIC) {
+        // not a clean control block (fresh or overwritten memory): no counter in it can be trusted.  Everybody raises the
+        // abort word (the gated launch tests != 0) and leaves; the fall-back computes the call and its last workgroup
+        // writes a clean block.
+        __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the clean-up's own counter starts from zero
+        sh[0] = -1; sh[1] = 0; sh[2] = 0;
+    } else if (threadIdx.x == 0 && ld_poll(&ctl->abort_)) {   // launch already marked as failed (diagnostics): nobody forms a team
         sh[0] = -1; sh[1] = 0; sh[2] = 0;
     } else if (threadIdx.x == 0) {
         const unsigned x = xcc_id();

@@ -91,10 +91,34 @@ _WS_CACHE_MAX = 8
 _capturing = getattr(torch.cuda, "is_current_stream_capturing", None)
 
 
+_ws_override: list = []      # innermost `workspace_override` first
+
+
+class workspace_override:
+    """``with workspace_override(ws):`` -- every loss launch inside that does not name a workspace uses ``ws`` (if it is big
+    enough and on the right device).  For a caller that OWNS the lifetime question, e.g. a HIP-graph capture: the
+    workspace is allocated and initialised once, outside the capture, lives as long as the object that holds the graph,
+    and the captured step has no allocation / initialisation node of its own (graphed.GraphedLossStep)."""
+
+    def __init__(self, ws: torch.Tensor):
+        self.ws = ws
+
+    def __enter__(self):
+        _ws_override.insert(0, self.ws)
+        return self.ws
+
+    def __exit__(self, *exc):
+        _ws_override.remove(self.ws)
+        return False
+
+
 def _workspace_for(lib, dev: torch.device, stream: int, key: tuple) -> torch.Tensor:
     need = _ws_bytes_cache.get(key)
     if need is None:
         need = _ws_bytes_cache[key] = int(lib.ge2e_workspace_bytes(*key[:6]))
+    for ws in _ws_override:
+        if ws.device == dev and ws.numel() >= need:
+            return ws
     if _capturing is not None and _capturing():
         return alloc_workspace(need, dev)
     k = (key[6], stream)
@@ -118,8 +142,15 @@ def resolve_impl(B: int, N: int, M: int, D: int, variant: str = "softmax", impl:
 
 
 def alloc_workspace(nbytes: int, device) -> torch.Tensor:
+    """A workspace tensor with the team kernel's control block written (ge2e_workspace_init: one small launch on the
+    current stream, no sync), so that the first call on it already runs the team kernel.  The block is self-cleaning
+    afterwards; an uninitialised workspace would also be safe, its first call would merely take the fall-back."""
     # torch's caching allocator returns >= 512-byte aligned blocks; the library wants 256
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    if ws.is_cuda:
+        with torch.cuda.device(ws.device):
+            _lib.check(_lib.load().ge2e_workspace_init(ws.data_ptr(), ws.numel(), _stream_ptr(ws)), "ge2e_workspace_init")
+    return ws
 
 
 def _check_scalar_params(w: torch.Tensor, b: torch.Tensor, dev: torch.device):
@@ -130,6 +161,13 @@ def _check_scalar_params(w: torch.Tensor, b: torch.Tensor, dev: torch.device):
             raise TypeError(f"{name} must be a float32 scalar tensor")
         if t.device != dev:
             raise RuntimeError(f"{name} is on {t.device}, embeddings on {dev}: raw pointers cross the C ABI, all on one device")
+
+
+def workspace_fallback_count(workspace: torch.Tensor) -> int:
+    """Diagnostic (one host sync): how many calls on this workspace were computed by the team kernel's in-call fall-back --
+    no team formed, a hand-off timed out beside another stream's kernels, or the control block was not clean -- since
+    `alloc_workspace` / `ge2e_workspace_init`.  (TeamCtl.fallbacks, csrc/ge2e_team.hpp: byte 1664 of the workspace.)"""
+    return int(workspace[1664:1668].view(torch.int32).item())
 
 
 @dataclass

@@ -34,19 +34,25 @@ class GraphedLossStep:
         self.input = torch.zeros(*shape, dtype=torch.float32, device=dev).requires_grad_(True)
         with torch.no_grad():   # something finite to warm up on
             self.input.copy_(torch.nn.functional.normalize(torch.randn(*shape, device=dev), dim=-1))
+        # the step's workspace: allocated and initialised HERE, outside the capture, owned by this object (the library's
+        # control block cleans itself after every call, so the captured step needs no initialisation node)
+        from . import functional as GF
+        n_, m_, d_ = (int(x) for x in shape)
+        self.workspace = GF.alloc_workspace(
+            GF.workspace_bytes(1, n_, m_, d_, getattr(loss_module, "variant", "softmax"), getattr(loss_module, "impl", "auto")), dev)
         if direct:
             self._capture_direct(dev, warmup)
             return
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):       # torch's capture recipe: warm up on a side stream
+        with torch.cuda.stream(side), GF.workspace_override(self.workspace):       # torch's capture recipe: warm up on a side stream
             for _ in range(max(1, warmup)):
                 self._zero()
                 self.module(self.input).backward()
         torch.cuda.current_stream(dev).wait_stream(side)
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph), GF.workspace_override(self.workspace):
             self.loss = self.module(self.input)
             self.loss.backward()
         self.input_grad = self.input.grad
@@ -62,7 +68,7 @@ class GraphedLossStep:
         w, b = m.w.detach(), m.b.detach()
 
         def launch():
-            GF.loss_fwd_bwd(e4, w, b, eps=eps, variant=m.variant, impl=m.impl, out=out)
+            GF.loss_fwd_bwd(e4, w, b, eps=eps, variant=m.variant, impl=m.impl, out=out, workspace=self.workspace)
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

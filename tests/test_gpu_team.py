@@ -269,3 +269,38 @@ def test_thousand_batches_through_one_team(GF, shape, per_team):
     num = (o.dE - of.dE).flatten(1).norm(dim=1)
     den = of.dE.flatten(1).norm(dim=1)
     assert float((num / den).max()) < 5e-6
+
+
+def test_control_block_cleans_itself(GF):
+    """Round 4: no zeroing launch in front of the team kernel.  A call leaves the control block clean (its gated launch's
+    last workgroup rewrites it), a workspace that was never initialised -- or that another implementation has written
+    over -- makes the call fall back ONCE and come out clean, and `workspace_fallback_count` says which happened."""
+    dev = torch.device("cuda:0")
+    B, N, M, D = 5, 64, 10, 256
+    e = _device_batches(B, N, M, D, 13)
+    w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+    nbytes = GF.workspace_bytes(B, N, M, D, "softmax", "team")
+    ws_ok = GF.alloc_workspace(nbytes, dev)                                    # initialised: team from the first call on
+    ref = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws_ok)
+    torch.cuda.synchronize()
+    assert GF.workspace_fallback_count(ws_ok) == 0
+    ws_raw = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device=dev)        # garbage where the control block goes
+    o1 = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws_raw)               # -> in-call fall-back, block cleaned up
+    torch.cuda.synchronize()
+    assert GF.workspace_fallback_count(ws_raw) == 1
+    assert torch.allclose(o1.loss, ref.loss, rtol=2e-6) and float(((o1.dE - ref.dE).norm() / ref.dE.norm())) < 5e-6
+    for _ in range(3):                                                          # ... and team ever after, bit for bit
+        o2 = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws_raw)
+        torch.cuda.synchronize()
+        assert torch.equal(o2.loss, ref.loss) and torch.equal(o2.dE, ref.dE) and torch.equal(o2.dw, ref.dw)
+    assert GF.workspace_fallback_count(ws_raw) == 1
+    # another implementation writes over the head of the same workspace in between
+    big = max(nbytes, GF.workspace_bytes(B, N, M, D, "softmax", "tiled"))
+    ws = GF.alloc_workspace(big, dev)
+    GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws)
+    GF.loss_fwd_bwd(e, w, b, impl="tiled", workspace=ws)
+    o3 = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws)
+    o4 = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.allclose(o3.loss, ref.loss, rtol=2e-6) and torch.equal(o4.dE, ref.dE)
+    assert float(((o3.dE - ref.dE).norm() / ref.dE.norm())) < 5e-6

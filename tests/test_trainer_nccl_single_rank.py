@@ -64,16 +64,17 @@ def test_auto_impl_beside_rccl_allreduce():
             tr.step(mel)
         torch.cuda.synchronize()
         times, aborted = [], 0
+        base = GF.workspace_fallback_count(GF._ws_cache[(dev.index, GF._stream_ptr(mel))])
         for _ in range(200):
             t0 = time.perf_counter()
             lv = tr.step(mel)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
             assert bool(torch.isfinite(lv))
-            # TeamCtl.abort_: second 128-byte line of the control block of THIS stream's workspace (other streams' cached
-            # workspaces -- a graph capture of another test -- were last written by other kernels)
+            # TeamCtl.fallbacks of THIS stream's workspace: calls whose abort word was up (the block cleans itself after
+            # every call, the count survives)
             ws = GF._ws_cache[(dev.index, GF._stream_ptr(mel))]
-            aborted += int(ws[128:132].view(torch.int32).item() != 0)
+            aborted = GF.workspace_fallback_count(ws) - base
         med, p95, worst = float(np.median(times)), float(np.percentile(times, 95)), float(np.max(times))
         print(f"single-rank RCCL trainer step: median {med * 1e6:.0f} us, p95 {p95 * 1e6:.0f} us, worst {worst * 1e6:.0f} us, "
               f"aborts {aborted}")
