@@ -162,6 +162,26 @@ int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const flo
 int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
                        const float* g_per, float* d_sim, void* stream);
 
+/*
+ * The static helpers on LOCAL ROWS -- the speaker-sharded exact loss: a rank holds the rows of the n
+ * speakers j0 .. j0 + n - 1 of a batch of N speakers and has gathered all N centroids.  Same semantics as
+ * get_cos_sim(embeddings, centroids) (s3:42-80: the caller's centroids on every other-speaker column, the leave-one-out
+ * centroid of the LOCAL rows on the own column j0 + jl) and calc_loss (s3:114-127), restricted to those rows:
+ *   E   [B][n][M][D]   C [B][N][D]   cos / sim / g_cos / d_sim [B][n][M][N]   loss [B]   per_emb_loss [B][n][M]
+ *   dE  [B][n][M][D]   dC [B][N][D] = this shard's PARTIAL centroid gradient (summed over the shards by the caller)
+ * n = N, j0 = 0 is exactly ge2e_cos_sim_centroids / ge2e_cos_sim_bwd / ge2e_calc_loss / ge2e_calc_loss_bwd.
+ */
+int ge2e_cos_sim_rows(const float* E, const float* C, int B, int n, int N, int j0, int M, int D, float eps_cos, float eps,
+                      float* cos, void* stream);
+size_t ge2e_cos_sim_rows_bwd_workspace_bytes(int B, int n, int N, int M, int D);
+int ge2e_cos_sim_rows_bwd(const float* E, const float* C, const float* cos, const float* g_cos, int B, int n, int N, int j0,
+                          int M, int D, float eps_cos, float eps, float* dE, float* dC, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int ge2e_calc_loss_rows(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, float* loss,
+                        float* per_emb_loss, void* stream);
+int ge2e_calc_loss_rows_bwd(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, const float* g_loss,
+                            const float* g_per, float* d_sim, void* stream);
+
 /* What `loss.backward()` (s4:200) does with the results of ge2e_loss_fwd_bwd: scale by the incoming gradient g (device;
  * g_count = 1 for a scalar loss or B for a per-batch loss vector) in ONE launch:
  *   gE [B][N][M][D] = g[b] dE[b]   (NULL: skip);   gw [1] = sum_b g[b] dw[b];   gb [1] = sum_b g[b] db[b]   (NULL: skip) */

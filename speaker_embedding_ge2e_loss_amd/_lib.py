@@ -53,6 +53,11 @@ PROTOTYPES = {
     "ge2e_cos_sim_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp,
                                    _fp, C.c_size_t, _fp]),
     "ge2e_calc_loss_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp, _fp]),
+    "ge2e_cos_sim_rows": (C.c_int, [_fp, _fp] + [C.c_int] * 6 + [C.c_float, C.c_float, _fp, _fp]),
+    "ge2e_cos_sim_rows_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "ge2e_cos_sim_rows_bwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 6 + [C.c_float, C.c_float, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ge2e_calc_loss_rows": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, _fp, _fp, _fp]),
+    "ge2e_calc_loss_rows_bwd": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, _fp, _fp, _fp, _fp]),
     "ge2e_normalize_unperm": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ge2e_normalize_unperm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_eer_counts": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp]),

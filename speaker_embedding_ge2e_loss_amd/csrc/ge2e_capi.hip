@@ -211,7 +211,7 @@ int ge2e_cos_sim_centroids(const float* E, const float* C, int B, int N, int M, 
                            float* cos, void* stream) {
     if (!E || !C || !cos) return GE2E_ERR_NULL;
     if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
-    return (int)launch_cos_centroids(E, C, B, N, M, D, eps_cos, eps, cos, (hipStream_t)stream);
+    return (int)launch_cos_centroids(E, C, B, N, N, 0, M, D, eps_cos, eps, cos, (hipStream_t)stream);
 }
 
 int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
@@ -219,7 +219,7 @@ int ge2e_calc_loss(const float* sim, int B, int N, int M, float eps, int variant
     if (!sim || !loss) return GE2E_ERR_NULL;
     if (B < 1 || N < 1 || M < 1) return GE2E_ERR_SHAPE;
     if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
-    return (int)launch_calc_loss(sim, B, N, M, eps, variant, loss, per_emb_loss, (hipStream_t)stream);
+    return (int)launch_calc_loss(sim, B, N, N, 0, M, eps, variant, loss, per_emb_loss, (hipStream_t)stream);
 }
 
 int ge2e_centroids(const float* E, int B, int N, int M, int D, float* cent, void* stream) {
@@ -241,7 +241,7 @@ int ge2e_centroids_bwd(const float* g_cent, int B, int N, int M, int D, float* d
 }
 
 size_t ge2e_cos_sim_bwd_workspace_bytes(int B, int N, int M, int D) {
-    return shape_ok(B, N, M, D) ? cos_bwd_workspace_bytes(B, N, M, D) : 0;
+    return shape_ok(B, N, M, D) ? cos_bwd_workspace_bytes(B, N, N, M, D) : 0;
 }
 
 int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const float* g_cos, int B, int N, int M, int D,
@@ -249,8 +249,8 @@ int ge2e_cos_sim_bwd(const float* E, const float* C, const float* cos, const flo
                      void* stream) {
     if (!E || !C || !cos || !g_cos || !dE || !dC) return GE2E_ERR_NULL;
     if (!shape_ok(B, N, M, D)) return GE2E_ERR_SHAPE;
-    if (!workspace || workspace_bytes < cos_bwd_workspace_bytes(B, N, M, D) || ((uintptr_t)workspace & 15)) return GE2E_ERR_WORKSPACE;
-    return (int)launch_cos_bwd(E, C, cos, g_cos, B, N, M, D, eps_cos, eps, dE, dC, (float*)workspace, (hipStream_t)stream);
+    if (!workspace || workspace_bytes < cos_bwd_workspace_bytes(B, N, N, M, D) || ((uintptr_t)workspace & 15)) return GE2E_ERR_WORKSPACE;
+    return (int)launch_cos_bwd(E, C, cos, g_cos, B, N, N, 0, M, D, eps_cos, eps, dE, dC, (float*)workspace, (hipStream_t)stream);
 }
 
 int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* g_loss,
@@ -258,7 +258,43 @@ int ge2e_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int var
     if (!sim || !d_sim || (!g_loss && !g_per)) return GE2E_ERR_NULL;
     if (B < 1 || N < 1 || M < 1) return GE2E_ERR_SHAPE;
     if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
-    return (int)launch_calc_loss_bwd(sim, B, N, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
+    return (int)launch_calc_loss_bwd(sim, B, N, N, 0, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
+}
+
+// ---- the same helpers on LOCAL ROWS (the speaker-sharded loss, s3:42-80 / s3:114-127 semantics) --------------
+static bool rows_ok(int B, int n, int N, int j0, int M, int D) {
+    return B >= 1 && n >= 1 && N >= 1 && M >= 2 && D >= 1 && j0 >= 0 && j0 + n <= N;
+}
+int ge2e_cos_sim_rows(const float* E, const float* C, int B, int n, int N, int j0, int M, int D, float eps_cos, float eps,
+                      float* cos, void* stream) {
+    if (!E || !C || !cos) return GE2E_ERR_NULL;
+    if (!rows_ok(B, n, N, j0, M, D)) return GE2E_ERR_SHAPE;
+    return (int)launch_cos_centroids(E, C, B, n, N, j0, M, D, eps_cos, eps, cos, (hipStream_t)stream);
+}
+size_t ge2e_cos_sim_rows_bwd_workspace_bytes(int B, int n, int N, int M, int D) {
+    return rows_ok(B, n, N, 0, M, D) ? cos_bwd_workspace_bytes(B, n, N, M, D) : 0;
+}
+int ge2e_cos_sim_rows_bwd(const float* E, const float* C, const float* cos, const float* g_cos, int B, int n, int N, int j0,
+                          int M, int D, float eps_cos, float eps, float* dE, float* dC, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (!E || !C || !cos || !g_cos || !dE || !dC) return GE2E_ERR_NULL;
+    if (!rows_ok(B, n, N, j0, M, D)) return GE2E_ERR_SHAPE;
+    if (!workspace || workspace_bytes < cos_bwd_workspace_bytes(B, n, N, M, D) || ((uintptr_t)workspace & 15)) return GE2E_ERR_WORKSPACE;
+    return (int)launch_cos_bwd(E, C, cos, g_cos, B, n, N, j0, M, D, eps_cos, eps, dE, dC, (float*)workspace, (hipStream_t)stream);
+}
+int ge2e_calc_loss_rows(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, float* loss,
+                        float* per_emb_loss, void* stream) {
+    if (!sim || !loss) return GE2E_ERR_NULL;
+    if (!rows_ok(B, n, N, j0, M, 1)) return GE2E_ERR_SHAPE;
+    if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    return (int)launch_calc_loss(sim, B, n, N, j0, M, eps, variant, loss, per_emb_loss, (hipStream_t)stream);
+}
+int ge2e_calc_loss_rows_bwd(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, const float* g_loss,
+                            const float* g_per, float* d_sim, void* stream) {
+    if (!sim || !d_sim || (!g_loss && !g_per)) return GE2E_ERR_NULL;
+    if (!rows_ok(B, n, N, j0, M, 1)) return GE2E_ERR_SHAPE;
+    if (variant != GE2E_VARIANT_SOFTMAX && variant != GE2E_VARIANT_CONTRAST) return GE2E_ERR_VARIANT;
+    return (int)launch_calc_loss_bwd(sim, B, n, N, j0, M, eps, variant, g_loss, g_per, d_sim, (hipStream_t)stream);
 }
 
 int ge2e_scale_grads(const float* dE, const float* dw, const float* db, const float* g, int g_count, int B, int N, int M,

@@ -232,16 +232,19 @@ __global__ void ge2e_centroids_kernel(const float* E, int rows /*B*N*/, int M, i
 // column and the leave-one-out centroid of `embeddings` on the own-speaker column): one wave per row r = (j, i).
 //   cos[r][k] = e_r . c_k / (max(|e_r|, eps_cos) max(|c_k|, eps_cos)) + eps            (k != j)
 //   cos[r][j] = e_r . u_r / (max(|e_r|, eps_cos) max(|u_r|, eps_cos)) + eps,  u_r = (sum_i' e_ji' - e_r) / (M - 1)
-// E [B][N][M][D], C [B][N][D] -> cos [B][N][M][N].  A forward-only helper (the eval script's path), not a hot path.
-__global__ __launch_bounds__(256) void ge2e_cos_centroids_kernel(const float* E, const float* C, int B, int N, int M,
-                                                                  int D, float eps_cos, float eps, float* cos) {
+// E [B][n][M][D], C [B][N][D] -> cos [B][n][M][N].  A forward-only helper (the eval script's path), not a hot path.
+// LOCAL ROWS (the speaker-sharded loss): E holds the rows of the n speakers j0 .. j0 + n - 1 of a batch of N
+// speakers whose centroids are all in C; the own-speaker column of local speaker jl is j0 + jl.  n = N, j0 = 0 is the
+// reference's get_cos_sim(embeddings, centroids).
+__global__ __launch_bounds__(256) void ge2e_cos_centroids_kernel(const float* E, const float* C, int B, int n, int N, int j0,
+                                                                  int M, int D, float eps_cos, float eps, float* cos) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    const size_t rows = (size_t)B * N * M;
+    const size_t rows = (size_t)B * n * M;
     for (size_t r = (size_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
-        const size_t bj = r / M;                    // (batch, speaker)
-        const int j = (int)(bj % N);
-        const size_t bi = bj / N;
+        const size_t bj = r / M;                    // (batch, local speaker)
+        const int j = j0 + (int)(bj % n);           // its column
+        const size_t bi = bj / n;
         const float* e = E + r * D;
         const float* spk = E + bj * (size_t)M * D;
         const float inv_m1 = 1.0f / (float)(M - 1);
@@ -270,26 +273,27 @@ __global__ __launch_bounds__(256) void ge2e_cos_centroids_kernel(const float* E,
     }
 }
 
-hipError_t launch_cos_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos, float eps,
-                                float* cos, hipStream_t stream) {
-    const size_t rows = (size_t)B * N * M;
+hipError_t launch_cos_centroids(const float* E, const float* C, int B, int n, int N, int j0, int M, int D, float eps_cos,
+                                float eps, float* cos, hipStream_t stream) {
+    const size_t rows = (size_t)B * n * M;
     const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
-    hipLaunchKernelGGL(ge2e_cos_centroids_kernel, dim3(grid), dim3(256), 0, stream, E, C, B, N, M, D, eps_cos, eps, cos);
+    hipLaunchKernelGGL(ge2e_cos_centroids_kernel, dim3(grid), dim3(256), 0, stream, E, C, B, n, N, j0, M, D, eps_cos, eps, cos);
     return hipGetLastError();
 }
 
 // calc_loss (s3:115-127) on an explicit similarity matrix: one wave per (speaker, utterance)
 // row, one workgroup per batch so the batch sum is a fixed-order reduction.
-__global__ __launch_bounds__(256) void ge2e_calc_loss_kernel(const float* sim, int B, int N, int M,
+// (local rows: sim [B][n M][N], the own-speaker column of row r is j0 + r / M; n = N, j0 = 0 is the reference's calc_loss)
+__global__ __launch_bounds__(256) void ge2e_calc_loss_kernel(const float* sim, int B, int n, int N, int j0, int M,
                                                              float eps, float log_eps, int variant,
                                                              float* loss, float* per) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, NW = blockDim.x >> 6;
     __shared__ float red[kMaxWaves];
     for (int bi = blockIdx.x; bi < B; bi += gridDim.x) {
         float acc = 0.f;
-        for (int r = wid; r < N * M; r += NW) {
-            const int j = r / M;
-            const float* row = sim + ((size_t)bi * N * M + r) * N;
+        for (int r = wid; r < n * M; r += NW) {
+            const int j = j0 + r / M;
+            const float* row = sim + ((size_t)bi * n * M + r) * N;
             const float sjj = row[j];
             float v;
             if (variant == 0) {
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void ge2e_calc_loss_kernel(const float* sim, i
                 v = 1.0f - 1.0f / (1.0f + expf(-sjj)) + neg;
             }
             acc += v;
-            if (per && lane == 0) per[(size_t)bi * N * M + r] = v;
+            if (per && lane == 0) per[(size_t)bi * n * M + r] = v;
         }
         if (lane == 0) red[wid] = acc;
         __syncthreads();
@@ -321,10 +325,10 @@ __global__ __launch_bounds__(256) void ge2e_calc_loss_kernel(const float* sim, i
     }
 }
 
-hipError_t launch_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
+hipError_t launch_calc_loss(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, float* loss,
                             float* per, hipStream_t stream) {
     const float log_eps = eps > 0.f ? logf(eps) : -INFINITY;
-    hipLaunchKernelGGL(ge2e_calc_loss_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sim, B, N,
+    hipLaunchKernelGGL(ge2e_calc_loss_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sim, B, n, N, j0,
                        M, eps, log_eps, variant, loss, per);
     return hipGetLastError();
 }

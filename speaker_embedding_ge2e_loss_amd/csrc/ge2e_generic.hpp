@@ -28,10 +28,11 @@ __host__ __device__ inline GenericLayout generic_layout(int N, int M, int D) {
 int generic_grid(int B);
 size_t generic_workspace_bytes(int B, int N, int M, int D);
 hipError_t launch_generic(const Problem& p, hipStream_t stream);
-hipError_t launch_calc_loss(const float* sim, int B, int N, int M, float eps, int variant, float* loss,
+// n local speakers whose columns are j0 .. j0 + n - 1 of N (n = N, j0 = 0: the whole batch)
+hipError_t launch_calc_loss(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant, float* loss,
                             float* per, hipStream_t stream);
-hipError_t launch_cos_centroids(const float* E, const float* C, int B, int N, int M, int D, float eps_cos, float eps,
-                                float* cos, hipStream_t stream);
+hipError_t launch_cos_centroids(const float* E, const float* C, int B, int n, int N, int j0, int M, int D, float eps_cos,
+                                float eps, float* cos, hipStream_t stream);
 hipError_t launch_centroids(const float* E, int B, int N, int M, int D, float* cent, hipStream_t stream);
 
 }  // namespace ge2e

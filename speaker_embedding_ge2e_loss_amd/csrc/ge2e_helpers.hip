@@ -38,35 +38,45 @@ __global__ __launch_bounds__(256) void centroids_bwd_kernel(const float* g, int 
 }
 
 // ---- get_cos_sim backward, three small launches (the boundaries are the synchronisation) ---------------------------
-// K0: speaker sums S[b][j][:] and the centroid scalars CS[b][k] = (1 / max(|c_k|, eps), kappa_k)
-__global__ __launch_bounds__(64) void cos_bwd_k0(const float* E, const float* C, int N, int M, int D, float eps_cos,
+// Local rows everywhere below (ge2e_generic.hip: ge2e_cos_centroids_kernel): E / dE hold the rows of the n speakers whose
+// columns are j0 .. j0 + n - 1 of the N centroids in C; dC is then this shard's PARTIAL centroid gradient (the sharded
+// loss sums it over the ranks with a reduce-scatter).  n = N, j0 = 0: the whole batch.
+// K0: speaker sums S[b][jl][:] (block < n) and the centroid scalars CS[b][k] = (1 / max(|c_k|, eps), kappa_k) (block < N)
+__global__ __launch_bounds__(64) void cos_bwd_k0(const float* E, const float* C, int n, int N, int M, int D, float eps_cos,
                                                  float* S, float* CS) {
-    const int b = blockIdx.x / N, j = blockIdx.x % N, lane = threadIdx.x;
-    const float* e = E + ((size_t)b * N + j) * M * D;
-    float sq = 0.f;
-    for (int d = lane; d < D; d += kWave) {
-        float s = 0.f;
-        for (int i = 0; i < M; ++i) s += e[(size_t)i * D + d];
-        S[((size_t)b * N + j) * D + d] = s;
-        const float c = C[((size_t)b * N + j) * D + d];
-        sq += c * c;
+    const int nb = n > N ? n : N;
+    const int b = blockIdx.x / nb, j = blockIdx.x % nb, lane = threadIdx.x;
+    if (j < n) {
+        const float* e = E + ((size_t)b * n + j) * M * D;
+        for (int d = lane; d < D; d += kWave) {
+            float s = 0.f;
+            for (int i = 0; i < M; ++i) s += e[(size_t)i * D + d];
+            S[((size_t)b * n + j) * D + d] = s;
+        }
     }
-    sq = wave_sum(sq);
-    float rn, kap;
-    unit_stats(sq, eps_cos, rn, kap);
-    if (lane == 0) { CS[((size_t)b * N + j) * 2] = rn; CS[((size_t)b * N + j) * 2 + 1] = kap; }
+    if (j < N) {
+        float sq = 0.f;
+        for (int d = lane; d < D; d += kWave) {
+            const float c = C[((size_t)b * N + j) * D + d];
+            sq += c * c;
+        }
+        sq = wave_sum(sq);
+        float rn, kap;
+        unit_stats(sq, eps_cos, rn, kap);
+        if (lane == 0) { CS[((size_t)b * N + j) * 2] = rn; CS[((size_t)b * N + j) * 2 + 1] = kap; }
+    }
 }
 
 // K1: one wave per row r = (j, i): the a-slot part of dE_r and the leave-one-out slot vector du_r
 //   g_e = sum_{k != j} g[r][k] c-hat_k + g[r][j] u-hat_r ;  dE_r = (g_e - kappa_e (g_e . e-hat) e-hat) / n_e
 //   du_r = g[r][j] (e-hat_r - kappa_u cos_rj u-hat_r) / n_u          (cos values come from the saved forward result)
 __global__ __launch_bounds__(64) void cos_bwd_k1(const float* E, const float* C, const float* cosv, const float* gcos,
-                                                 const float* S, const float* CS, int N, int M, int D, float eps_cos,
-                                                 float eps, float* dE, float* DU, float* RNE) {
-    const int NM = N * M;
-    const int b = blockIdx.x / NM, r = blockIdx.x % NM, j = r / M, lane = threadIdx.x;
+                                                 const float* S, const float* CS, int n, int N, int j0, int M, int D,
+                                                 float eps_cos, float eps, float* dE, float* DU, float* RNE) {
+    const int NM = n * M;                               // local rows per batch
+    const int b = blockIdx.x / NM, r = blockIdx.x % NM, jl = r / M, j = j0 + jl, lane = threadIdx.x;
     const float* e = E + ((size_t)b * NM + r) * D;
-    const float* s = S + ((size_t)b * N + j) * D;
+    const float* s = S + ((size_t)b * n + jl) * D;
     const float* g = gcos + ((size_t)b * NM + r) * N;
     const float* cv = cosv + ((size_t)b * NM + r) * N;
     const float inv_m1 = 1.0f / (float)(M - 1);
@@ -112,32 +122,33 @@ __global__ __launch_bounds__(256) void cos_bwd_k2a(const float* DU, int speakers
 
 // K2b: one wave per centroid k: dC_k = (g_c - kappa_c (g_c . c-hat_k) c-hat_k) / n_c,  g_c = sum_{r not of k} g[r][k] e-hat_r
 __global__ __launch_bounds__(64) void cos_bwd_k2b(const float* E, const float* C, const float* cosv, const float* gcos,
-                                                  const float* CS, const float* RNE, int N, int M, int D, float eps,
-                                                  float* dC) {
-    const int NM = N * M;
+                                                  const float* CS, const float* RNE, int n, int N, int j0, int M, int D,
+                                                  float eps, float* dC) {
+    const int NM = n * M;                               // local rows per batch
     const int b = blockIdx.x / N, k = blockIdx.x % N, lane = threadIdx.x;
     const float rnc = CS[((size_t)b * N + k) * 2], kc = CS[((size_t)b * N + k) * 2 + 1];
     float t = 0.f;
     for (int r = lane; r < NM; r += kWave)
-        if (r / M != k) t += gcos[((size_t)b * NM + r) * N + k] * (cosv[((size_t)b * NM + r) * N + k] - eps);
+        if (j0 + r / M != k) t += gcos[((size_t)b * NM + r) * N + k] * (cosv[((size_t)b * NM + r) * N + k] - eps);
     t = wave_sum(t);
     for (int d = lane; d < D; d += kWave) {
         float gc = 0.f;
         for (int r = 0; r < NM; ++r)
-            if (r / M != k) gc += gcos[((size_t)b * NM + r) * N + k] * E[((size_t)b * NM + r) * D + d] * RNE[(size_t)b * NM + r];
+            if (j0 + r / M != k) gc += gcos[((size_t)b * NM + r) * N + k] * E[((size_t)b * NM + r) * D + d] * RNE[(size_t)b * NM + r];
         const float ch = C[((size_t)b * N + k) * D + d] * rnc;
         dC[((size_t)b * N + k) * D + d] = (gc - kc * t * ch) * rnc;
     }
 }
 
 // ---- calc_loss backward: dS[r][k] = gl[b] * dL_r/dS_rk + gp[r] * (the same), one wave per row ----------------------
-__global__ __launch_bounds__(256) void calc_loss_bwd_kernel(const float* sim, int B, int N, int M, float eps, float log_eps,
-                                                            int variant, const float* gloss, const float* gper, float* dS) {
+__global__ __launch_bounds__(256) void calc_loss_bwd_kernel(const float* sim, int B, int n, int N, int j0, int M, float eps,
+                                                            float log_eps, int variant, const float* gloss, const float* gper,
+                                                            float* dS) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, NW = blockDim.x >> 6;
-    const size_t rows = (size_t)B * N * M;
+    const size_t rows = (size_t)B * n * M;
     for (size_t r = (size_t)blockIdx.x * NW + wid; r < rows; r += (size_t)gridDim.x * NW) {
-        const int j = (int)((r % ((size_t)N * M)) / M);
-        const size_t bi = r / ((size_t)N * M);
+        const int j = j0 + (int)((r % ((size_t)n * M)) / M);
+        const size_t bi = r / ((size_t)n * M);
         const float* row = sim + r * N;
         float* out = dS + r * N;
         const float gr = (gloss ? gloss[bi] : 0.f) + (gper ? gper[r] : 0.f);
@@ -225,28 +236,29 @@ hipError_t launch_centroids_bwd(const float* g, int B, int N, int M, int D, floa
     return hipGetLastError();
 }
 
-size_t cos_bwd_workspace_bytes(int B, int N, int M, int D) {
-    return ((size_t)B * N * D + (size_t)B * N * M * D + (size_t)B * N * M + (size_t)B * N * 2) * sizeof(float);
+size_t cos_bwd_workspace_bytes(int B, int n, int N, int M, int D) {
+    return ((size_t)B * n * D + (size_t)B * n * M * D + (size_t)B * n * M + (size_t)B * N * 2) * sizeof(float);
 }
 
-hipError_t launch_cos_bwd(const float* E, const float* C, const float* cosv, const float* gcos, int B, int N, int M, int D,
-                          float eps_cos, float eps, float* dE, float* dC, float* ws, hipStream_t stream) {
+hipError_t launch_cos_bwd(const float* E, const float* C, const float* cosv, const float* gcos, int B, int n, int N, int j0,
+                          int M, int D, float eps_cos, float eps, float* dE, float* dC, float* ws, hipStream_t stream) {
     float* S = ws;
-    float* DU = S + (size_t)B * N * D;
-    float* RNE = DU + (size_t)B * N * M * D;
-    float* CS = RNE + (size_t)B * N * M;
-    hipLaunchKernelGGL(cos_bwd_k0, dim3(B * N), dim3(64), 0, stream, E, C, N, M, D, eps_cos, S, CS);
-    hipLaunchKernelGGL(cos_bwd_k1, dim3(B * N * M), dim3(64), 0, stream, E, C, cosv, gcos, S, CS, N, M, D, eps_cos, eps, dE, DU, RNE);
-    hipLaunchKernelGGL(cos_bwd_k2a, dim3(grid_for((size_t)B * N * D, 256)), dim3(256), 0, stream, DU, B * N, M, D, dE);
-    hipLaunchKernelGGL(cos_bwd_k2b, dim3(B * N), dim3(64), 0, stream, E, C, cosv, gcos, CS, RNE, N, M, D, eps, dC);
+    float* DU = S + (size_t)B * n * D;
+    float* RNE = DU + (size_t)B * n * M * D;
+    float* CS = RNE + (size_t)B * n * M;
+    hipLaunchKernelGGL(cos_bwd_k0, dim3(B * (n > N ? n : N)), dim3(64), 0, stream, E, C, n, N, M, D, eps_cos, S, CS);
+    hipLaunchKernelGGL(cos_bwd_k1, dim3(B * n * M), dim3(64), 0, stream, E, C, cosv, gcos, S, CS, n, N, j0, M, D, eps_cos, eps,
+                       dE, DU, RNE);
+    hipLaunchKernelGGL(cos_bwd_k2a, dim3(grid_for((size_t)B * n * D, 256)), dim3(256), 0, stream, DU, B * n, M, D, dE);
+    hipLaunchKernelGGL(cos_bwd_k2b, dim3(B * N), dim3(64), 0, stream, E, C, cosv, gcos, CS, RNE, n, N, j0, M, D, eps, dC);
     return hipGetLastError();
 }
 
-hipError_t launch_calc_loss_bwd(const float* sim, int B, int N, int M, float eps, int variant, const float* gloss,
-                                const float* gper, float* dS, hipStream_t stream) {
+hipError_t launch_calc_loss_bwd(const float* sim, int B, int n, int N, int j0, int M, float eps, int variant,
+                                const float* gloss, const float* gper, float* dS, hipStream_t stream) {
     const float log_eps = eps > 0.f ? logf(eps) : -INFINITY;
-    hipLaunchKernelGGL(calc_loss_bwd_kernel, dim3(grid_for((size_t)B * N * M, 4)), dim3(256), 0, stream, sim, B, N, M, eps,
-                       log_eps, variant, gloss, gper, dS);
+    hipLaunchKernelGGL(calc_loss_bwd_kernel, dim3(grid_for((size_t)B * n * M, 4)), dim3(256), 0, stream, sim, B, n, N, j0, M,
+                       eps, log_eps, variant, gloss, gper, dS);
     return hipGetLastError();
 }
 

@@ -366,6 +366,99 @@ def cos_sim(embeddings: torch.Tensor, centroids: torch.Tensor | None = None, *, 
     return cos[0] if squeeze else cos
 
 
+class _CosSimRowsFunction(torch.autograd.Function):
+    """get_cos_sim on the rows of n speakers (columns j0 .. j0 + n - 1) against all N centroids (ge2e_cos_sim_rows)."""
+
+    @staticmethod
+    def forward(ctx, e3, c2, j0, eps, eps_cos):
+        lib = _lib.load()
+        n, M, D = e3.shape
+        N = c2.shape[0]
+        cos = torch.empty(n, M, N, dtype=torch.float32, device=e3.device)
+        with torch.cuda.device(e3.device):
+            code = lib.ge2e_cos_sim_rows(e3.data_ptr(), c2.data_ptr(), 1, n, N, j0, M, D, eps_cos, eps, cos.data_ptr(),
+                                         _stream_ptr(e3))
+        _lib.check(code, "ge2e_cos_sim_rows")
+        ctx.save_for_backward(e3, c2, cos)
+        ctx.j0, ctx.eps, ctx.eps_cos = j0, eps, eps_cos
+        return cos
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        e3, c2, cos = ctx.saved_tensors
+        n, M, D = e3.shape
+        N = c2.shape[0]
+        g = g.contiguous().float()
+        dE, dC = torch.empty_like(e3), torch.empty_like(c2)
+        ws = torch.empty(max(int(lib.ge2e_cos_sim_rows_bwd_workspace_bytes(1, n, N, M, D)), 256), dtype=torch.uint8, device=e3.device)
+        with torch.cuda.device(e3.device):
+            code = lib.ge2e_cos_sim_rows_bwd(e3.data_ptr(), c2.data_ptr(), cos.data_ptr(), g.data_ptr(), 1, n, N, ctx.j0, M, D,
+                                             ctx.eps_cos, ctx.eps, dE.data_ptr(), dC.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _stream_ptr(e3))
+        _lib.check(code, "ge2e_cos_sim_rows_bwd")
+        return dE, dC, None, None, None
+
+
+class _CalcLossRowsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s3, j0, eps, variant):
+        lib = _lib.load()
+        n, M, N = s3.shape
+        loss = torch.empty(1, dtype=torch.float32, device=s3.device)
+        per = torch.empty(n, M, dtype=torch.float32, device=s3.device)
+        with torch.cuda.device(s3.device):
+            code = lib.ge2e_calc_loss_rows(s3.data_ptr(), 1, n, N, j0, M, eps, _lib.VARIANTS[variant], loss.data_ptr(),
+                                           per.data_ptr(), _stream_ptr(s3))
+        _lib.check(code, "ge2e_calc_loss_rows")
+        ctx.save_for_backward(s3)
+        ctx.j0, ctx.eps, ctx.variant = j0, eps, variant
+        return loss[0], per
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, g_per):
+        lib = _lib.load()
+        (s3,) = ctx.saved_tensors
+        n, M, N = s3.shape
+        gl = g_loss.reshape(1).contiguous().float() if g_loss is not None else None
+        gp = g_per.contiguous().float() if g_per is not None else None
+        dS = torch.empty_like(s3)
+        with torch.cuda.device(s3.device):
+            code = lib.ge2e_calc_loss_rows_bwd(s3.data_ptr(), 1, n, N, ctx.j0, M, ctx.eps, _lib.VARIANTS[ctx.variant],
+                                               gl.data_ptr() if gl is not None else None,
+                                               gp.data_ptr() if gp is not None else None, dS.data_ptr(), _stream_ptr(s3))
+        _lib.check(code, "ge2e_calc_loss_rows_bwd")
+        return dS, None, None, None
+
+
+def cos_sim_rows(embeddings: torch.Tensor, centroids: torch.Tensor, first_speaker: int, *, eps: float = SMALL_ERR,
+                 eps_cos: float = EPS_COS) -> torch.Tensor:
+    """get_cos_sim (s3:42-80) restricted to LOCAL ROWS: ``embeddings`` (n,M,D) are the rows of speakers ``first_speaker`` ..
+    ``first_speaker + n - 1`` of a batch whose N centroids are ``centroids`` (N,D) -> (n,M,N); the own-speaker column of
+    local speaker jl is ``first_speaker + jl`` and carries the cosine with the leave-one-out centroid of the local rows.
+    Differentiable in both arguments (the centroid gradient is this shard's partial one).  SURVEY 8e-ii."""
+    _require_cuda(embeddings, "embeddings")
+    _require_cuda(centroids, "centroids")
+    if embeddings.dim() != 3 or centroids.dim() != 2 or centroids.shape[1] != embeddings.shape[2]:
+        raise ValueError(f"cos_sim_rows: embeddings (n,M,D) and centroids (N,D), got {tuple(embeddings.shape)}, {tuple(centroids.shape)}")
+    n, N = embeddings.shape[0], centroids.shape[0]
+    if first_speaker < 0 or first_speaker + n > N:
+        raise ValueError(f"cos_sim_rows: speakers {first_speaker}..{first_speaker + n - 1} of {N}")
+    return _CosSimRowsFunction.apply(embeddings.contiguous().float(), centroids.contiguous().float(), int(first_speaker),
+                                     float(eps), float(eps_cos))
+
+
+def calc_loss_rows(sim_rows: torch.Tensor, first_speaker: int, *, eps: float = SMALL_ERR, variant: str = "softmax"):
+    """calc_loss (s3:114-127) on the similarity rows (n,M,N) of speakers ``first_speaker`` ..: (sum of the per-row losses,
+    per-row losses (n,M)); differentiable."""
+    _require_cuda(sim_rows, "sim_rows")
+    if sim_rows.dim() != 3:
+        raise ValueError(f"sim_rows must be (n,M,N), got {tuple(sim_rows.shape)}")
+    return _CalcLossRowsFunction.apply(sim_rows.contiguous().float(), int(first_speaker), float(eps), variant)
+
+
 def centroids(embeddings: torch.Tensor) -> torch.Tensor:
     """get_centroids (s3:34-38): mean over the utterance axis."""
     _require_cuda(embeddings, "embeddings")

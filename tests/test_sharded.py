@@ -184,3 +184,76 @@ def test_gpu_single_rank_nccl_group():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_gpu_local_rows_helpers_equal_the_whole_batch_ones(variant):
+    """ge2e_cos_sim_rows / ge2e_calc_loss_rows (+ backward) on a slice of speakers against the whole-batch helpers: the
+    slice's similarity rows, per-row losses, row gradients and the PARTIAL centroid gradient."""
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+    dev = torch.device("cuda:0")
+    N, M, D, j0, n = 24, 5, 96, 8, 6
+    e = torch.from_numpy(orc.synth_embeddings((N, M, D), "raw", seed=9)).float().to(dev)
+    c = torch.randn(N, D, device=dev)                       # the caller's centroids: NOT the means of e
+    gsim = torch.randn(n, M, N, device=dev)
+    # whole batch through the reference-shaped helpers; gradient only through the slice's rows of the output
+    ef = e.clone().requires_grad_(True); cf = c.clone().requires_grad_(True)
+    cos_f = GF.cos_sim(ef, cf)
+    (cos_f[j0:j0 + n] * gsim).sum().backward()
+    el = e[j0:j0 + n].clone().requires_grad_(True); cl = c.clone().requires_grad_(True)
+    cos_l = GF.cos_sim_rows(el, cl, j0)
+    (cos_l * gsim).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(cos_l, cos_f[j0:j0 + n], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(el.grad, ef.grad[j0:j0 + n], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(cl.grad, cf.grad, rtol=1e-5, atol=1e-6)      # only the slice's rows carried a gradient
+    assert float(ef.grad[:j0].abs().max()) == 0.0
+    # calc_loss
+    sf = (7.5 * cos_f.detach() - 2.0).requires_grad_(True)
+    sl = (7.5 * cos_l.detach() - 2.0).requires_grad_(True)
+    _, per_f = GF.calc_loss(sf, variant=variant)
+    loss_l, per_l = GF.calc_loss_rows(sl, j0, variant=variant)
+    per_f[j0:j0 + n].sum().backward()
+    loss_l.backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(per_l, per_f[j0:j0 + n], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(loss_l, per_f[j0:j0 + n].sum(), rtol=1e-6)
+    assert torch.allclose(sl.grad, sf.grad[j0:j0 + n], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_local_rows_beat_the_padded_composition():
+    """N = 256 in 8 shards on one device: the local-rows kernels against round 3's padded composition (the local rows in
+    an (N,M,D) block of zeros): same loss and gradients, and the time of one shard's forward + backward."""
+    import time
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+    dev = torch.device("cuda:0")
+    N, M, D, world = 256, 10, 256, 8
+    n = N // world
+    e = torch.from_numpy(orc.synth_embeddings((N, M, D), "unit", seed=5)).float().to(dev)
+    cents = GF.centroids(e).detach()
+    out = {}
+    for padded in (False, True):
+        def one():
+            a = e[3 * n:4 * n].clone().requires_grad_(True)
+            w = torch.tensor(10.0, device=dev, requires_grad=True)
+            b = torch.tensor(-5.0, device=dev, requires_grad=True)
+            cc = cents.clone().requires_grad_(True)
+            loss = sharded.sharded_ge2e_loss(a, w, b, 3, world, gather=lambda c_: cc, padded=padded)
+            loss.backward()
+            return loss.detach(), a.grad, cc.grad, w.grad
+        for _ in range(3):
+            r = one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            r = one()
+        torch.cuda.synchronize()
+        out[padded] = (r, (time.perf_counter() - t0) / 10)
+    (l0, g0, c0, w0), t_rows = out[False]
+    (l1, g1, c1, w1), t_pad = out[True]
+    print(f"sharded loss, one of 8 shards of N=256: local rows {t_rows * 1e6:.0f} us, padded {t_pad * 1e6:.0f} us")
+    assert torch.allclose(l0, l1, rtol=2e-6) and torch.allclose(g0, g1, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(c0, c1, rtol=1e-4, atol=1e-6) and torch.allclose(w0, w1, rtol=1e-5)
+    assert t_rows < t_pad
