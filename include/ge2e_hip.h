@@ -19,6 +19,9 @@
  *   - the caller owns every buffer including the workspace; the library
  *     allocates nothing, keeps no state and never synchronises: calls only
  *     enqueue work on `stream` (a hipStream_t passed as void*, NULL = default);
+ *   - a loss workspace (ge2e_workspace_bytes) begins with a 26 KB control block
+ *     of the eight-CU team kernel, whichever implementation runs on it; the
+ *     block cleans itself after every call (see ge2e_workspace_init);
  *   - w and b (s3:16-17) are read from device memory, no host sync;
  *   - return value: 0 = ok, < 0 = argument error (GE2E_ERR_*), > 0 = hipError_t
  *     of a failed launch.  Nothing is thrown across the boundary.
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GE2E_ABI_VERSION 1
+#define GE2E_ABI_VERSION 2   /* 2: ge2e_workspace_init, the *_rows helpers; every loss workspace starts with the control block */
 
 /* loss variants: eq. (6) softmax is the reference's (s3:115-127); eq. (7)
  * contrast is defined from arXiv:1710.10467 (absent from the reference). */

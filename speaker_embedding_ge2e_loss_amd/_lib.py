@@ -10,7 +10,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VARIANT_SOFTMAX, VARIANT_CONTRAST = 0, 1
 VARIANTS = {"softmax": VARIANT_SOFTMAX, "contrast": VARIANT_CONTRAST}

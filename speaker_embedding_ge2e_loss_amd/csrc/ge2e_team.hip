@@ -16,14 +16,15 @@
 //        (60 MFMAs a wave, SIMD-balanced)
 //   S    softmax / contrast on X, 16 lanes per row: leave-one-out statistics, loss, dL/dS -> G images, row coefficients
 //   F    FINISH of prev: the seven other members' partial gradients of my speaker (+ my own slice, kept in LDS) -> KJ_j;
-//        KJP_j of cur
+//        of cur only a scalar is left (KJP_j = kjb c-hat_j: the leave-one-out speaker row's e-hat part rides in gC, see S)
 //   dE   dE(prev) = held + KJ_j -> HBM in whole 128-byte lines (the only write of dE)
 //   GC   partial gC^T[d][k] = sum_r ET[r][d] G[r][k] (32 x 32 x 16 tiles) -> published for the next iteration's F
 //   --   the next batch's rows requested (the only read of E)
 //   GE   gE[d][r] = sum_k CH[k][d] G[r][k] with the centroid fragments from registers; ra gE + c1 e-hat is held in
 //        registers (40 VGPRs) until the partial gradients of the other members arrive
-// The own-speaker column of a row carries the coefficient of s_j in the G image (so GE adds that term for free);
-// what that entry adds to the member's own partial gC is taken out again algebraically in KJ_j (see S).
+// The own-speaker column of a row carries the coefficient of s_j in the G image (so GE adds that term for free); what
+// that entry adds to the member's own partial gC IS, pushed through the centroid norm, the leave-one-out speaker row
+// sum_i c3_i e-hat_i up to a multiple of c-hat_j (see S): nothing has to be taken out or added as a vector.
 //
 // Exchange per batch and team: 128 KB of centroids (two layouts, double-buffered by batch parity) + 448 KB of partial
 // gradients in ONE buffer guarded by a read-done counter (c3); measured fabric traffic 1.4x the algorithmic bytes.
@@ -924,12 +925,10 @@ _Pragma("unroll")                                                               
         __syncthreads();
         GE2E_PROF(4);
 
-        // F2 (vector work on the images) and GC (matrix pipe, stores) are independent: opposite order on the two waves of
-        // a SIMD, as for dE / X above
         // GE's centroid fragments (k-group form, published in this iteration's A1) are requested HERE, in front of the two
-        // phases that issue no memory instruction (F2 is vector work, GC's contraction reads LDS): the address path is
-        // idle now and saturated behind GC's contraction, where these eight 1-KB loads per wave used to stand in front of
-        // the read-done poll and the 32 partial-gradient stores.  (32 registers live through F2 and GC.)
+        // phases that issue no memory instruction (F2 is a scalar reduction now, GC's contraction reads LDS): the address
+        // path is idle now and saturated behind GC's contraction, where these eight 1-KB loads per wave used to stand in
+        // front of the read-done poll and the 32 partial-gradient stores.  (32 registers live through F2 and GC.)
 #define T2_GA_LOAD()                                                                                                      \
     do {                                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < NTI; ++i) {                                                                 \
@@ -943,7 +942,7 @@ _Pragma("unroll")                                                               
         }                                                                                                                 \
     } while (0)
         if (want_grad) { GE2E_T2_LANE(); T2_GA_LOAD(); }
-        // ===== F2: member scalars out; KJP'_j of cur (wave-local: it stays in registers until the next F1) ==========
+        // ===== F2: member scalars out; the coefficient of KJP_j = kjb c-hat_j of cur (kept in a register until the next F1) =
         if (have_cur && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
 #pragma unroll
@@ -957,9 +956,6 @@ _Pragma("unroll")                                                               
         }
         GE2E_PROF(12);
         if (want_grad) {
-            // GE's centroid fragments (k-group form) are requested AFTER GC's contraction, when its operand fragments are
-            // dead (requested before it they cost 32 more registers under the accumulators and the allocator spilled
-            // them); the answers land under the read-done wait and the partial-gradient stores
             // ===== GC: partial gC[k][d] = sum_r G[r][k] ET[r][d]; wave: slots 32 kh.., columns 64 sl.. ===============
             {
                 GE2E_T2_LANE();

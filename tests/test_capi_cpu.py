@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.ge2e_abi_version() == 1
+    assert lib.ge2e_abi_version() == 2
     assert lib.ge2e_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.ge2e_strerror(code)) > 3
