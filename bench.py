@@ -413,6 +413,14 @@ def main():
         for _ in range(10):
             module_step()
         extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+        # ... and with the autograd node in Python (functional._GE2ELossFunction) instead of libge2e_torch.so's: same launches
+        extra["latency_module_autograd_node"] = "c++ (libge2e_torch.so)" if GF._cpp_loss_op() is not None else "python"
+        if GF._cpp_loss_op() is not None:
+            GF.use_cpp_autograd(False)
+            for _ in range(10):
+                module_step()
+            extra["latency_module_python_node_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+            GF.use_cpp_autograd(True)
         # the same step captured once in a HIP graph and replayed (graphed.GraphedLossStep): the host work of the eager
         # module path -- Python, autograd dispatch, allocator -- leaves the loop, the device operations stay.  Measured in
         # a CHILD process: graph capture exercises runtime paths nothing else here does, and whatever happens to it must

@@ -15,6 +15,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libge2e_hip.so")
+TORCH_EXT_SRC = os.path.join(PKG_DIR, "csrc_torch", "ge2e_autograd.cpp")
+TORCH_EXT_PATH = os.path.join(PKG_DIR, "libge2e_torch.so")      # the autograd node in C++ (host code only, links libge2e_hip.so)
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 ARCH = "gfx950"
 
@@ -71,6 +73,7 @@ def _compile_one(args):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every csrc/*.hip to an object (in parallel, only the stale ones) and link one shared object."""
     if not force and not is_stale():
+        build_torch_ext(force=False, verbose=verbose)
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -89,7 +92,38 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("[ge2e build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    build_torch_ext(force=True, verbose=verbose)
     return LIB_PATH
+
+
+def torch_ext_is_stale() -> bool:
+    if not os.path.exists(TORCH_EXT_PATH):
+        return True
+    t = os.path.getmtime(TORCH_EXT_PATH)
+    return any(os.path.getmtime(d) > t for d in [TORCH_EXT_SRC] + glob.glob(os.path.join(INCLUDE, "*.h")))
+
+
+def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
+    """g++ the C++ autograd node (csrc_torch/ge2e_autograd.cpp: torch.ops.ge2e_amd.loss) against this interpreter's torch
+    and the in-tree libge2e_hip.so.  Host code only -- every kernel stays in libge2e_hip.so."""
+    if not force and not torch_ext_is_stale():
+        return TORCH_EXT_PATH
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found (needed for libge2e_torch.so)")
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-Wno-deprecated-declarations",
+           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", f"-I{INCLUDE}",
+           TORCH_EXT_SRC, "-o", TORCH_EXT_PATH + ".tmp", f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+           "-ltorch_hip", f"-L{PKG_DIR}", "-lge2e_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir}/lib"]
+    if verbose:
+        print("[ge2e build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(TORCH_EXT_PATH + ".tmp", TORCH_EXT_PATH)
+    return TORCH_EXT_PATH
 
 
 def build_variant(out_path: str, defs: list[str], verbose: bool = False) -> str:

@@ -704,6 +704,29 @@ class _GE2ELossFunction(torch.autograd.Function):
         return gE, gw, gb, None, None, None, None
 
 
+# The autograd node in C++ (libge2e_torch.so, csrc_torch/ge2e_autograd.cpp: torch.ops.ge2e_amd.loss): the same two C-ABI
+# calls as _GE2ELossFunction without the Python dispatch around them -- the eager module step at B = 1 is host-bound.
+# Used when the library has been built (build.build() does); _GE2ELossFunction is the same node in Python.
+_cpp_node = {"tried": False, "op": None, "enabled": True}
+
+
+def _cpp_loss_op():
+    if not _cpp_node["tried"]:
+        _cpp_node["tried"] = True
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libge2e_torch.so")
+        if os.path.exists(path):
+            _lib.load()                                   # the core library first: missing -> the loud error, not a dlopen one
+            torch.ops.load_library(path)
+            _cpp_node["op"] = torch.ops.ge2e_amd.loss
+    return _cpp_node["op"] if _cpp_node["enabled"] else None
+
+
+def use_cpp_autograd(enabled: bool) -> None:
+    """Choose between the C++ autograd node (default when libge2e_torch.so is built) and the Python one (same launches)."""
+    _cpp_node["enabled"] = bool(enabled)
+
+
 def ge2e_loss(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, eps: float = SMALL_ERR,
               eps_cos: float = EPS_COS, variant: str = "softmax", impl: str = "auto") -> torch.Tensor:
     """Differentiable GE2E loss: 0-dim for (N,M,D) input, (B,) for (B,N,M,D)."""
@@ -713,5 +736,9 @@ def ge2e_loss(embeddings: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, eps
         # the reference is dtype-generic (s3:19-30 accepts fp16 / fp64 and returns that dtype); the kernels
         # compute in fp32, the casts either side are differentiable torch ops
         embeddings = embeddings.float()
-    loss = _GE2ELossFunction.apply(embeddings, w, b, float(eps), float(eps_cos), variant, impl)
+    op = None if _ws_override else _cpp_loss_op()         # (a caller-owned workspace -- a graph capture -- goes through Python)
+    if op is not None:
+        loss = op(embeddings, w, b, float(eps), float(eps_cos), _lib.VARIANTS[variant], _lib.IMPLS[impl])
+    else:
+        loss = _GE2ELossFunction.apply(embeddings, w, b, float(eps), float(eps_cos), variant, impl)
     return loss if in_dtype == torch.float32 else loss.to(in_dtype)

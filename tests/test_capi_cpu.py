@@ -114,3 +114,15 @@ def test_product_refuses_cpu_tensors():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.GE2ELibraryError, match="not built"):
         _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_cpp_autograd_library_builds_loads_and_refuses_cpu_tensors():
+    """libge2e_torch.so (the autograd node in C++): built next to libge2e_hip.so, registers torch.ops.ge2e_amd.loss, and has
+    no CPU path either."""
+    import torch
+    from speaker_embedding_ge2e_loss_amd import build, functional as GF
+    assert os.path.exists(build.build_torch_ext(force=False, verbose=False))
+    op = GF._cpp_loss_op()
+    assert op is not None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        op(torch.randn(4, 5, 8), torch.tensor(10.0), torch.tensor(-5.0), 1e-6, 1e-8, 0, 0)

@@ -405,3 +405,37 @@ def test_tiled_fused_similarity_and_row_pass(GF, shape, variant):
     torch.cuda.synchronize()
     assert np.allclose(o.loss.cpu().numpy(), ref["loss"], rtol=2e-5)
     assert np.allclose(o.per.cpu().numpy(), ref["per"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(64, 10, 256), (4, 5, 256), (3, 64, 10, 256)])
+def test_cpp_autograd_node_equals_the_python_one(GF, shape):
+    """torch.ops.ge2e_amd.loss (libge2e_torch.so) against functional._GE2ELossFunction: the same two C-ABI calls, so loss
+    and every gradient agree bit for bit -- scalar loss of one batch, and a (B,) loss vector with a vector of incoming grads."""
+    if GF._cpp_loss_op() is None:
+        pytest.fail("libge2e_torch.so is not built (speaker_embedding_ge2e_loss_amd.build.build_torch_ext)")
+    dev = torch.device("cuda:0")
+    E = orc.synth_embeddings(shape, "unit", seed=8)
+    res = []
+    for cpp in (True, False):
+        GF.use_cpp_autograd(cpp)
+        e = torch.as_tensor(E, device=dev).requires_grad_(True)
+        w = torch.tensor(10.0, device=dev, requires_grad=True)
+        b = torch.tensor(-5.0, device=dev, requires_grad=True)
+        loss = GF.ge2e_loss(e, w, b)
+        if loss.dim() == 0:
+            loss.backward()
+        else:
+            loss.backward(torch.linspace(0.5, 1.5, loss.numel(), device=dev))
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), e.grad.clone(), w.grad.clone(), b.grad.clone()))
+    GF.use_cpp_autograd(True)
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    assert res[0][2].shape == torch.Size([]) and res[0][0].shape == (torch.Size([]) if len(shape) == 3 else torch.Size([shape[0]]))
+    with torch.no_grad():                                   # forward only through the op (dE = NULL inside)
+        e = torch.as_tensor(E, device=dev)
+        l2 = GF.ge2e_loss(e, torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev))
+    assert torch.allclose(l2, res[0][0], rtol=1e-6)
+    ref = orc.closed_form(E if len(shape) == 3 else E[0], 10.0, -5.0)
+    got = float(res[0][0]) if len(shape) == 3 else float(res[0][0][0])
+    assert abs(got - ref["loss"]) <= 2e-5 * abs(ref["loss"])
