@@ -64,14 +64,30 @@ struct Problem {
 #define GE2E_PROF_FLUSH(n)                                             \
     if (threadIdx.x == GE2E_PROF_TID && p.prof)                                    \
         for (int prof_i = 0; prof_i < n; ++prof_i) atomicAdd(p.prof + prof_i, prof_acc[prof_i]);
+#define GE2E_PROF_FLUSH_AT(base, n)                                    \
+    if (threadIdx.x == GE2E_PROF_TID && p.prof)                                    \
+        for (int prof_i = 0; prof_i < n; ++prof_i) atomicAdd(p.prof + (base) + prof_i, prof_acc[prof_i]);
+/* a stamp taken inside a callee (`t`: its s_memtime) closes phase i */
+#define GE2E_PROF_AT(i, t)                                             \
+    do {                                                               \
+        prof_acc[i] += (t) - prof_last;                                \
+        prof_last = (t);                                               \
+    } while (0)
+#define GE2E_PROF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #elif defined(GE2E_MARKS)   // ISA reading aid: phase boundaries as comments in the -save-temps assembly, no code
 #define GE2E_PROF_DECL(n)
 #define GE2E_PROF(i) asm volatile("; PHASEMARK " #i)
 #define GE2E_PROF_FLUSH(n)
+#define GE2E_PROF_FLUSH_AT(base, n)
+#define GE2E_PROF_AT(i, t)
+#define GE2E_PROF_DRAIN()
 #else
 #define GE2E_PROF_DECL(n)
 #define GE2E_PROF(i)
 #define GE2E_PROF_FLUSH(n)
+#define GE2E_PROF_FLUSH_AT(base, n)
+#define GE2E_PROF_AT(i, t)
+#define GE2E_PROF_DRAIN()
 #endif
 
 // ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps), no LDS round trips ----

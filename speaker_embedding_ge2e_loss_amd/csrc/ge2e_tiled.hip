@@ -89,6 +89,11 @@ struct GemmCfg {
     static constexpr int STAGES = TM_ == 256 ? 2 : 1;
     static constexpr int STAGE_HALFS = 2 * (PLANE_A + PLANE_B);
     static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_HALFS * sizeof(_Float16);
+    static constexpr bool DMA = false;
+};
+// the big tile with its operands brought in by buffer_load ... lds (gemm_tile_dma below; K a multiple of 32)
+struct GemmCfgDma : GemmCfg<256, 256> {
+    static constexpr bool DMA = true;
 };
 
 struct Opnd {
@@ -203,13 +208,234 @@ __device__ __forceinline__ h8 gemm_frag(const _Float16* t, int blk0, int s, int 
     return frag_tr(t, T + 16, 16 * s, blk0, lane);
 }
 
+// ---- the 256 x 256 tile with the operands brought into LDS by the memory pipe itself (buffer_load ... lds) ---------------
+// Round 4, SQ counters of the register-staged loop at config 5: the matrix pipe busy a third of the time, LDS cycles about
+// equal to MFMA cycles (every K-step each wave spends 16 ds_write_b128 = 208 cycles on the store path and the transposing
+// reads of the [KS][T + 16] image collide two-way), 64 VGPRs of prefetch next to 128 accumulators.  Here a K-step's four
+// planes (A hi/lo, B hi/lo: 4 x 16 KB) arrive as 64 one-KiB pieces, eight per wave, with no register in between; a piece's
+// LDS bytes are lane-linear (that is what the instruction does), so the images are unpadded and the bank spread comes
+// from which GLOBAL 16 bytes a lane fetches (the read side applies the same exclusive-or):
+//   K-rows plane  [32 K-rows][256 cols]: 512-byte rows; 64-byte column chunk c of row r sits at chunk position c ^ (r & 3)
+//                 -- the transposing read's four rows of one half-wave land on four different quarter rows of the banks;
+//   K-contig plane [256 rows][32 K]:     64-byte rows; 16-byte piece p of row r sits at piece position p ^ ((r >> 2) & 3)
+//                 -- the sixteen rows of a ds_read_b128 lane group land on sixteen different 16-byte slots.
+// Needs ktotal % 32 == 0 (a K-contiguous piece past the end of K would read the next row); other shapes keep the loop above.
+constexpr int DMA_PL = 32 * 256;            // halfs per plane
+constexpr int DMA_ST = 4 * DMA_PL;          // halfs per stage (64 KB)
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+// per-lane byte offsets of this wave's two pieces (j = wave, wave + 8) of one operand's planes
+template <bool KC>
+__device__ __forceinline__ void dma_piece_offsets(const Opnd& o, int lane, int wid, unsigned (&vo)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = wid + 8 * jj;
+        if (KC) {   // piece = 16 rows x 64 B; lane -> row 16 j + lane / 4, LDS piece position lane & 3
+            const int row = 16 * j + (lane >> 2), pc = (lane & 3) ^ ((lane >> 4) & 3);
+            vo[jj] = row < o.valid ? (unsigned)(((size_t)row * o.ld + 8 * pc) * 2) : 0x7FFFFF00u;
+        } else {    // piece = 2 K-rows x 512 B; lane -> row 2 j + lane / 32, LDS chunk position (lane & 31) / 4
+            const int row = 2 * j + (lane >> 5), ch = ((lane & 31) >> 2) ^ (row & 3), c8 = 32 * ch + 8 * (lane & 3);
+            vo[jj] = c8 < o.valid ? (unsigned)(((size_t)row * o.ld + c8) * 2) : 0x7FFFFF00u;
+        }
+    }
+}
+// The pieces are issued from inline asm: hipcc counts a `buffer_load ... lds` it knows about as a store to every LDS
+// address and puts s_waitcnt vmcnt(0) in front of the next ds_read -- the fetch of K-step s + 1 would be drained before
+// the first fragment of step s is read (seen in the ISA of the builtin form).  M0 (the piece's LDS byte address) is written
+// in the statement that uses it; the wait is ours (dma_wait), in front of the barrier that hands the stage over.
+struct DmaRs { tu32x4 hi, lo; unsigned kstep_bytes; };
+template <class C, bool KC, int T>
+__device__ __forceinline__ DmaRs dma_rsrc(const Opnd& o, int ktotal) {
+    const size_t span = KC ? ((size_t)(o.valid - 1) * o.ld + (size_t)ktotal) * 2
+                           : ((size_t)(ktotal - 1) * o.ld + (size_t)((o.valid + 7) / 8 * 8)) * 2;
+    const unsigned long long ah = (unsigned long long)o.hi, al = (unsigned long long)o.lo;
+    DmaRs r;
+    r.hi = tu32x4{(unsigned)ah, (unsigned)(ah >> 32) & 0xFFFFu, (unsigned)span, 0x00020000u};
+    r.lo = tu32x4{(unsigned)al, (unsigned)(al >> 32) & 0xFFFFu, (unsigned)span, 0x00020000u};
+    r.kstep_bytes = KC ? (unsigned)C::KS * 2u : (unsigned)((size_t)C::KS * o.ld * 2);
+    return r;
+}
+__device__ __forceinline__ void dma_piece(const tu32x4& rs, unsigned lds_byte, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma_issue(const DmaRs& rA, const DmaRs& rB, const unsigned (&voA)[2], const unsigned (&voB)[2],
+                                          unsigned kA, unsigned kB, unsigned stage_byte, int wid) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const unsigned d = stage_byte + (unsigned)(wid + 8 * jj) * 1024u;
+        dma_piece(rA.hi, d, voA[jj], kA);
+        dma_piece(rA.lo, d + 2u * DMA_PL, voA[jj], kA);
+        dma_piece(rB.hi, d + 4u * DMA_PL, voB[jj], kB);
+        dma_piece(rB.lo, d + 6u * DMA_PL, voB[jj], kB);
+    }
+}
+// all but the n most recent memory instructions of this wave have completed (they complete in issue order)
+__device__ __forceinline__ void dma_wait_but(int n) {
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// fragment of 32-row / 32-column block `blk` (0..7 inside the tile) for K-slice s (16 K each) of a plane
+template <bool KC>
+__device__ __forceinline__ h8 dma_frag(const _Float16* pl, int blk, int s, int lane) {
+    if (KC) {
+        const int l31 = lane & 31, g = (l31 >> 2) & 3, pc = ((lane >> 5) + 2 * s) ^ g;
+        return frag_row(pl + (32 * blk + l31) * 32 + 8 * pc);
+    }
+    const int hh = lane >> 5, g2 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    const _Float16* p = pl + (16 * s + 8 * hh + q) * 256 + 32 * (blk ^ q) + 16 * g2 + 4 * pp;
+    const h4 t0 = tr_read4(p);
+    const h4 t1 = tr_read4(p + 4 * 256);
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+#ifdef GE2E_PROFILE
+#define DMA_STAMP(i)                                                          \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+        if (t_first) t_first[i] += now_ - last_;                              \
+        last_ = now_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
+#else
+#define DMA_STAMP(i)
+#endif
+template <class C, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
+                                              f32x16 (&acc)[C::A2][C::B2], unsigned long long* t_first = nullptr) {
+    static_assert(C::TM == 256 && C::TN == 256 && C::KS == 32 && (size_t)2 * DMA_ST * 2 <= C::LDS_BYTES, "big tile only");
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wa = wid / C::WN, wb = wid % C::WN;
+    const int ablk0 = wa * C::A2, bblk0 = wb * C::B2;
+    const DmaRs rA = dma_rsrc<C, AKC, C::TM>(A, ktotal), rB = dma_rsrc<C, BKC, C::TN>(B, ktotal);
+    unsigned voA[2], voB[2];
+    dma_piece_offsets<AKC>(A, lane, wid, voA);
+    dma_piece_offsets<BKC>(B, lane, wid, voB);
+    const unsigned sm_byte = (unsigned)(unsigned long long)(lds_void_p)sm;
+    // Schedule of one K-step k (two 16-wide slices s0, s1; F0 / F1 = the twelve fragments of a slice, 48 VGPRs each):
+    //     read F1(k, s1)  |  24 MFMAs on F0(k, s0)      -- the reads return under the MFMAs
+    //     wait: own pieces of stage k + 1 landed; barrier  -- everybody has read all of stage k, stage k + 1 is whole
+    //     issue the pieces of K-step k + 2 into stage k's buffer
+    //     read F0(k + 1, s0)  |  24 MFMAs on F1(k, s1)
+    // A piece has a whole K-step (~1.3 us of MFMAs) to land, no fragment read is waited for with the matrix pipe idle, one
+    // barrier per K-step.  The sched_barriers pin the order (left alone hipcc moves the barrier up to the first MFMA).
+    const int nk = ktotal / 32;
+    unsigned kA = 0, kB = 0;
+    dma_issue(rA, rB, voA, voB, 0u, 0u, sm_byte, wid);
+    if (nk > 1) {
+        kA = rA.kstep_bytes; kB = rB.kstep_bytes;
+        dma_issue(rA, rB, voA, voB, kA, kB, sm_byte + 2u * DMA_ST, wid);
+        dma_wait_but(8);       // the eight pieces of step 0 (pieces land in issue order)
+    } else {
+        dma_wait();
+    }
+    __syncthreads();
+#ifdef GE2E_PROFILE
+    unsigned long long last_ = 0;
+    if (t_first) {   // diagnostic build: when the first stage had landed; [1..4]: the K-step's four parts, summed
+        __builtin_amdgcn_sched_barrier(0);
+        t_first[0] = last_ = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    h8 f0a[C::A2][2], f0b[C::B2][2], f1a[C::A2][2], f1b[C::B2][2];
+    // A slice's twelve fragment reads come in three chunks (B and A block 0 | A blocks 1, 2 | A block 3) and its 24 MFMAs
+    // in four groups of six (one A block each); chunk c of the NEXT slice is issued behind MFMA group c of the current
+    // one, so that after a barrier the matrix pipe starts at once and every read / piece issues in the shadow of an MFMA
+    // (stamped build, round 4: with all reads and pieces issued in front of the MFMAs both waves of a SIMD left the
+    // pipe idle for ~700 cycles after every barrier).
+    auto read_chunk = [&](const _Float16* st, int s, int c, h8 (&fa)[C::A2][2], h8 (&fb)[C::B2][2]) {
+        if (c == 0) {
+#pragma unroll
+            for (int u = 0; u < C::B2; ++u) {
+                fb[u][0] = dma_frag<BKC>(st + 2 * DMA_PL, bblk0 + u, s, lane);
+                fb[u][1] = dma_frag<BKC>(st + 3 * DMA_PL, bblk0 + u, s, lane);
+            }
+        }
+        const int lo = c == 0 ? 0 : c == 1 ? 1 : 3, hi = c == 0 ? 1 : c == 1 ? 3 : 4;
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2)
+            if (a2 >= lo && a2 < hi) {
+                fa[a2][0] = dma_frag<AKC>(st, ablk0 + a2, s, lane);
+                fa[a2][1] = dma_frag<AKC>(st + DMA_PL, ablk0 + a2, s, lane);
+            }
+    };
+    auto mfma_group = [&](int a2, const h8 (&fa)[C::A2][2], const h8 (&fb)[C::B2][2]) {
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2) acc[a2][b2] = mfma3(fa[a2][0], fa[a2][1], fb[b2][0], fb[b2][1], acc[a2][b2]);
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) read_chunk(sm, 0, c, f0a, f0b);
+    int cur = 0;
+    for (int k = 0; k < nk; ++k, cur ^= 1) {
+        const _Float16* const st = sm + cur * DMA_ST;
+        const _Float16* const nx = sm + (cur ^ 1) * DMA_ST;
+        const unsigned stage_byte = sm_byte + (unsigned)cur * (2u * DMA_ST);
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2) {          // slice 0 on the matrix pipe, slice 1 read behind it
+            if (a2 == 0) __builtin_amdgcn_s_setprio(1);
+            if (a2 == 2) __builtin_amdgcn_s_setprio(0);
+            mfma_group(a2, f0a, f0b);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a2 < 3) read_chunk(st, 1, a2, f1a, f1b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        DMA_STAMP(1);      // slice-1 reads + 24 MFMAs issued (the reads have returned)
+        dma_wait();        // this wave's pieces of stage k + 1 have landed ...
+        DMA_STAMP(2);
+        __syncthreads();   // ... and so have everybody else's; everybody has read all of stage k
+        __builtin_amdgcn_sched_barrier(0);
+        DMA_STAMP(3);      // the barrier
+        const bool more2 = k + 2 < nk, more1 = k + 1 < nk;
+        if (more2) { kA += rA.kstep_bytes; kB += rB.kstep_bytes; }
+        // Issue priority falls from barrier to barrier (3, 2 | 1, 0 over the eight MFMA groups of a K-step): of the two waves
+        // that share a SIMD the one that is BEHIND wins the arbiter.  With equal priorities the older wave wins every tie,
+        // finishes its K-step ~1200 cycles early and sits at the barrier while the other runs alone with every read and
+        // piece it issues exposed (stamped build, views of waves 0 and 4, round 4).
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2) {          // slice 1 on the matrix pipe; the pieces of K-step k + 2 (two per
+            if (a2 == 0) __builtin_amdgcn_s_setprio(3);   // group, into stage k's buffer) and slice 0 of step k + 1 behind it
+            if (a2 == 2) __builtin_amdgcn_s_setprio(2);
+            mfma_group(a2, f1a, f1b);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more2) {
+                const unsigned d = stage_byte + (unsigned)(wid + 8 * (a2 >> 1)) * 1024u;
+                if ((a2 & 1) == 0) {
+                    dma_piece(rA.hi, d, voA[a2 >> 1], kA);
+                    dma_piece(rA.lo, d + 2u * DMA_PL, voA[a2 >> 1], kA);
+                } else {
+                    dma_piece(rB.hi, d + 4u * DMA_PL, voB[a2 >> 1], kB);
+                    dma_piece(rB.lo, d + 6u * DMA_PL, voB[a2 >> 1], kB);
+                }
+            }
+            if (more1 && a2 < 3) read_chunk(nx, 0, a2, f0a, f0b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef GE2E_PROFILE
+        {   // 24 MFMAs + pieces + slice-0 reads issued; NOT waiting for the reads (they belong to the next step)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+            if (t_first) t_first[4] += now_ - last_;
+            last_ = now_;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+    }
+}
+
 // acc[a2][b2] += A[wave rows + 32 a2 ..][K] . B[wave cols + 32 b2 ..][K]  over K = [0, ktotal)
 template <class C, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
-                                          f32x16 (&acc)[C::A2][C::B2]) {
+                                          f32x16 (&acc)[C::A2][C::B2], unsigned long long* t_first = nullptr) {
     constexpr int KS = C::KS;
     const int lane = tid & 63, wid = tid >> 6, wa = wid / C::WN, wb = wid % C::WN;
     const int arow0 = wa * (32 * C::A2), bcol0 = wb * (32 * C::B2);
+    if constexpr (C::DMA) {   // (a kernel holds ONE of the two loops: with both, the waits hipcc places for the register
+        gemm_tile_dma<C, AKC, BKC>(A, B, ktotal, sm, tid, acc, t_first);   // prefetch of the other loop drain the pieces in flight)
+        return;
+    }
     uint4 pah[C::NP], pal[C::NP], pbh[C::NP], pbl[C::NP];
     gemm_fetch<C, AKC, C::TM>(A, 0, min(KS, ktotal), tid, pah, pal);
     gemm_fetch<C, BKC, C::TN>(B, 0, min(KS, ktotal), tid, pbh, pbl);
@@ -441,12 +667,8 @@ static void launch_prep(const Problem& p, const TiledWs& L, hipStream_t stream) 
 // (the centroid planes in k_sim / k_ge) -- land on eight different L2s and the shared operand is fetched eight times.
 // This gives the workgroups of ONE XCD a contiguous range of tile numbers instead.
 __device__ __forceinline__ int xcd_major_tile(unsigned b, unsigned grid) {
-#ifdef GE2E_X_TILED_NO_XCD_MAP
-    return (int)b;
-#else
     const unsigned per = grid / 8;
     return b < per * 8 ? (int)((b % 8) * per + b / 8) : (int)b;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,7 +693,14 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
     Bo.ld = D; Bo.valid = min(C::TN, N - kt * C::TN);
     f32x16 acc[C::A2][C::B2];
     gemm_zero<C>(acc);
-    gemm_tile<C, true, true>(A, Bo, D, gsm, tid, acc);
+    GE2E_PROF_DECL(8)
+    unsigned long long t_first[5] = {0, 0, 0, 0, 0};
+    gemm_tile<C, true, true>(A, Bo, D, gsm, tid, acc, t_first);
+    GE2E_PROF_AT(0, t_first[0]);
+    GE2E_PROF(1);
+#ifdef GE2E_PROFILE
+    for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
+#endif
     float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
     const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
@@ -489,6 +718,10 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
                         make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
             }
         }
+    GE2E_PROF(2);
+    GE2E_PROF_DRAIN();
+    GE2E_PROF(3);
+    GE2E_PROF_FLUSH_AT(0, 8)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1028,19 +1261,30 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) 
     const int dtiles = (D + C::TN - 1) / C::TN, ct = (N + C::TM - 1) / C::TM;
     int t = xcd_major_tile(blockIdx.x, gridDim.x);
     const int dt = t % dtiles; t /= dtiles;
-    const int kt = t % ct;
-    const int bi = t / ct;
+    const int kt = t % ct; t /= ct;
+    const int S = L.gc_split, sp = t % S;
+    const int bi = t / S;
+    // rows [r0, r1) of the batch: piece sp of S (whole 32-row K-steps when S > 1 -- the launcher splits only then)
+    const int steps = NM / 32;
+    const int r0 = S > 1 ? (int)((long long)steps * sp / S) * 32 : 0, r1 = S > 1 ? (int)((long long)steps * (sp + 1) / S) * 32 : NM;
     Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + kt * C::TM;
+    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r0 * npad + kt * C::TM;
     A.lo = A.hi + (size_t)NM * npad;
     A.ld = npad; A.valid = min(C::TM, npad - kt * C::TM);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + dt * C::TN;
+    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + (size_t)r0 * D + dt * C::TN;
     Bo.lo = Bo.hi + (size_t)NM * D;
     Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
     f32x16 acc[C::A2][C::B2];
     gemm_zero<C>(acc);
-    gemm_tile<C, false, false>(A, Bo, NM, gsm, tid, acc);
-    float* GC = p.ws + L.gc + (size_t)bi * N * D;
+    GE2E_PROF_DECL(8)
+    unsigned long long t_first[5] = {0, 0, 0, 0, 0};
+    gemm_tile<C, false, false>(A, Bo, r1 - r0, gsm, tid, acc, t_first);
+    GE2E_PROF_AT(0, t_first[0]);
+    GE2E_PROF(1);
+#ifdef GE2E_PROFILE
+    for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
+#endif
+    float* GC = S > 1 ? p.ws + L.x + ((size_t)bi * S + sp) * N * D : p.ws + L.gc + (size_t)bi * N * D;
     const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
 #pragma unroll
     for (int a2 = 0; a2 < C::A2; ++a2)
@@ -1057,6 +1301,10 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) 
                         make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
             }
         }
+    GE2E_PROF(2);
+    GE2E_PROF_DRAIN();
+    GE2E_PROF(3);
+    GE2E_PROF_FLUSH_AT(8, 8)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1069,7 +1317,8 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
     const int bi = gw / N, j = gw - bi * N;
     const float w = p.w ? *p.w : p.w_imm;
     const float fM = (float)M;
-    const float* GC = p.ws + L.gc + ((size_t)bi * N + j) * D;
+    const int S = L.gc_split;
+    const float* GC = S > 1 ? p.ws + L.x + ((size_t)bi * S * N + j) * D : p.ws + L.gc + ((size_t)bi * N + j) * D;
     const float* CHf = p.ws + L.chf + ((size_t)bi * N + j) * D;
     const float4 cs = *reinterpret_cast<const float4*>(p.ws + L.cst + ((size_t)bi * N + j) * 4);
     const float* RS = p.ws + L.rs + ((size_t)bi * NM + (size_t)j * M) * 8;
@@ -1082,7 +1331,12 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
         const int d = 256 * q + 4 * lane;
         g[q] = c[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < npass && d < D) {
-            g[q] = scale4(*reinterpret_cast<const float4*>(GC + d), w);
+            float4 gs = *reinterpret_cast<const float4*>(GC + d);
+            for (int sp = 1; sp < S; ++sp) {       // k_gc's partial sums, in a fixed order
+                const float4 gp = *reinterpret_cast<const float4*>(GC + (size_t)sp * N * D + d);
+                gs.x += gp.x; gs.y += gp.y; gs.z += gp.z; gs.w += gp.w;
+            }
+            g[q] = scale4(gs, w);
             c[q] = *reinterpret_cast<const float4*>(CHf + d);
             coef += dot4(g[q], c[q]);
         }
@@ -1141,7 +1395,14 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
     Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
     f32x16 acc[C::A2][C::B2];
     gemm_zero<C>(acc);
-    gemm_tile<C, true, false>(A, Bo, N, gsm, tid, acc);   // K = the N real centroid slots (pad columns of GH are zero)
+    GE2E_PROF_DECL(8)
+    unsigned long long t_first[5] = {0, 0, 0, 0, 0};
+    gemm_tile<C, true, false>(A, Bo, N, gsm, tid, acc, t_first);   // K = the N real centroid slots (pad columns of GH are zero)
+    GE2E_PROF_AT(0, t_first[0]);
+    GE2E_PROF(1);
+#ifdef GE2E_PROFILE
+    for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
+#endif
     const float* E = p.E + (size_t)bi * NM * D;
     float* dE = p.dE + (size_t)bi * NM * D;
     const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
@@ -1149,29 +1410,47 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
     // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
     // columns: every global access of the epilogue is 16 bytes wide (8 rows x 128 B per wave-instruction)
     const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
+    // The loads of a 32-row block (4 row scalars, 8 x 16 B of e, 8 x 16 B of KJ per lane: 72 VGPRs, free now that the
+    // fragments are dead) are all requested before the first is used, on clamped addresses so that no branch separates
+    // them: one memory round trip per block instead of one per 16 bytes (stamped build, config 5, round 4: the epilogue
+    // was 35 % of the workgroup's time at 12 GB/s per CU -- latency, not bandwidth).
 #pragma unroll
-    for (int a2 = 0; a2 < C::A2; ++a2)
+    for (int a2 = 0; a2 < C::A2; ++a2) {
+        float2 rs[4];
+        float4 e[4][C::B2], kj[4][C::B2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
-            const bool rv = r < NM;
-            const int rc = rv ? r : NM - 1;
-            const float2 rs = *reinterpret_cast<const float2*>(RS + (size_t)rc * 8);  // ra c1e
+            const int rc = r < NM ? r : NM - 1;
+            rs[g] = *reinterpret_cast<const float2*>(RS + (size_t)rc * 8);  // ra c1e
             const int j = rc / M;
+#pragma unroll
+            for (int b2 = 0; b2 < C::B2; ++b2) {
+                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
+                const int dc = d < D ? d : 0;
+                e[g][b2] = *reinterpret_cast<const float4*>(E + (size_t)rc * D + dc);
+                kj[g][b2] = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + dc);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
 #pragma unroll
             for (int b2 = 0; b2 < C::B2; ++b2) {
                 float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
                 quad_transpose4(x, lane);
                 const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
-                if (rv && d < D) {
-                    const float4 e = *reinterpret_cast<const float4*>(E + (size_t)r * D + d);
-                    const float4 kj = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + d);
+                if (r < NM && d < D)
                     *reinterpret_cast<float4*>(dE + (size_t)r * D + d) =
-                        make_float4(x[0] * rs.x + e.x * rs.y + kj.x, x[1] * rs.x + e.y * rs.y + kj.y,
-                                    x[2] * rs.x + e.z * rs.y + kj.z, x[3] * rs.x + e.w * rs.y + kj.w);
-                }
+                        make_float4(x[0] * rs[g].x + e[g][b2].x * rs[g].y + kj[g][b2].x, x[1] * rs[g].x + e[g][b2].y * rs[g].y + kj[g][b2].y,
+                                    x[2] * rs[g].x + e[g][b2].z * rs[g].y + kj[g][b2].z, x[3] * rs[g].x + e[g][b2].w * rs[g].y + kj[g][b2].w);
             }
         }
+    }
+    GE2E_PROF(2);
+    GE2E_PROF_DRAIN();
+    GE2E_PROF(3);
+    GE2E_PROF_FLUSH_AT(16, 8)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1249,19 +1528,22 @@ TiledWs tiled_layout(int B, int N, int M, int D) {
 size_t tiled_workspace_bytes(int B, int N, int M, int D) { return tiled_layout(B, N, M, D).total * sizeof(float); }
 
 hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
-    const TiledWs L = tiled_layout(p.B, p.N, p.M, p.D);
+    TiledWs L = tiled_layout(p.B, p.N, p.M, p.D);
     const int NM = p.N * p.M;
     const unsigned spk_blocks = (unsigned)((p.B * p.N + 3) / 4);
     const unsigned row_blocks = (unsigned)(((size_t)p.B * NM + 3) / 4);
     typedef GemmCfg<128, 128> C1;
     typedef GemmCfg<256, 256> C2;
+    typedef GemmCfgDma C3;   // the same tile, operands by LDS-DMA: the contraction's K must be a multiple of 32
     {   // every launch, like the fused kernels: the attribute is per device and a process may drive several
         const void* small[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C1>), reinterpret_cast<const void*>(ge2e_tiled_gc<C1>),
                                reinterpret_cast<const void*>(ge2e_tiled_ge<C1>)};
         const void* big[] = {reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), reinterpret_cast<const void*>(ge2e_tiled_gc<C2>),
                              reinterpret_cast<const void*>(ge2e_tiled_ge<C2>),
-                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, false, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, false, true>),
-                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, true, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C2, true, true>)};
+                             reinterpret_cast<const void*>(ge2e_tiled_sim<C3>), reinterpret_cast<const void*>(ge2e_tiled_gc<C3>),
+                             reinterpret_cast<const void*>(ge2e_tiled_ge<C3>),
+                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C3, false, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C3, false, true>),
+                             reinterpret_cast<const void*>(ge2e_tiled_simrows<C3, true, false>), reinterpret_cast<const void*>(ge2e_tiled_simrows<C3, true, true>)};
         for (const void* fn : small) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1::LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -1279,18 +1561,31 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     const bool big_gc = p.N >= 256 && p.D >= 256 && (unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) >= fill;
     const bool big_ge = NM >= 256 && p.D >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256) >= fill;
     // one 256-slot tile holds a whole similarity row: similarity contraction + row pass in one kernel (config 4)
-    const bool fused_rows = L.npad <= 256 && p.N > 128 && NM >= 256 && (unsigned)p.B * tiles(NM, 256) >= fill;
+    const bool fused_rows = L.npad <= 256 && p.N > 128 && NM >= 256 && p.D % 32 == 0 && (unsigned)p.B * tiles(NM, 256) >= fill;
+    // k_gc has B ct dtiles tiles, each over ALL rows of its batch: at config 5 that is 192 workgroups for 256 CUs, one
+    // round.  Cut the rows into S pieces when that fills the last round better (S = 4 there: three full rounds); the
+    // partial sums go to the similarity block, dead once the row pass has run, and k_spk adds them in a fixed order.
+    if (big_gc && NM % 32 == 0) {
+        const unsigned tiles_gc = (unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256);
+        auto fillq = [](unsigned wg) { return (double)wg / (double)((wg + 255) / 256 * 256); };
+        int best = 1;
+        for (int sp : {2, 4, 8})
+            if (NM / 32 >= 8 * sp && (size_t)sp * p.N * p.D <= (size_t)NM * L.npad && fillq(tiles_gc * sp) > fillq(tiles_gc * best) + 0.1) best = sp;
+        L.gc_split = best;
+    }
     launch_prep(p, L, stream);
     if (fused_rows) {
         const dim3 g((unsigned)p.B * tiles(NM, 256));
         if (p.variant == 1) {
-            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C2, true, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
-            else hipLaunchKernelGGL((ge2e_tiled_simrows<C2, true, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C3, true, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            else hipLaunchKernelGGL((ge2e_tiled_simrows<C3, true, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         } else {
-            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C2, false, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
-            else hipLaunchKernelGGL((ge2e_tiled_simrows<C2, false, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            if (p.N == 256) hipLaunchKernelGGL((ge2e_tiled_simrows<C3, false, true>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            else hipLaunchKernelGGL((ge2e_tiled_simrows<C3, false, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         }
-    } else if (big_sim)
+    } else if (big_sim && p.D % 32 == 0)
+        hipLaunchKernelGGL(ge2e_tiled_sim<C3>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
@@ -1300,12 +1595,16 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
     else
         hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
     if (p.dE) {
-        if (big_gc)
+        if (big_gc && NM % 32 == 0)
+            hipLaunchKernelGGL(ge2e_tiled_gc<C3>, dim3((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) * L.gc_split), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        else if (big_gc)
             hipLaunchKernelGGL(ge2e_tiled_gc<C2>, dim3((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else
             hipLaunchKernelGGL(ge2e_tiled_gc<C1>, dim3((unsigned)p.B * tiles(p.N, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
         hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
-        if (big_ge)
+        if (big_ge && p.N % 32 == 0)
+            hipLaunchKernelGGL(ge2e_tiled_ge<C3>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        else if (big_ge)
             hipLaunchKernelGGL(ge2e_tiled_ge<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else
             hipLaunchKernelGGL(ge2e_tiled_ge<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
@@ -1325,10 +1624,14 @@ hipError_t launch_tiled_cos(const Problem& p, hipStream_t stream) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_tiled_sim<C2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2::LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ge2e_tiled_sim<GemmCfgDma>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2::LDS_BYTES);
+    if (e != hipSuccess) return e;
     auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
     const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= 192;
     launch_prep(p, L, stream);
-    if (big_sim)
+    if (big_sim && p.D % 32 == 0)
+        hipLaunchKernelGGL(ge2e_tiled_sim<GemmCfgDma>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
         hipLaunchKernelGGL(ge2e_tiled_sim<C1>, dim3((unsigned)p.B * tiles(NM, 128) * tiles(p.N, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);

@@ -7,6 +7,7 @@ namespace ge2e {
 struct TiledWs {  // offsets in floats into the workspace
     size_t ch, eh, gh, chf, x, gc, kj, cst, rst, rs, total;
     int npad, row_tiles, cen_tiles;
+    int gc_split = 1;   // k_gc's contraction over the rows cut into this many pieces (partial sums in the dead X block; k_spk adds them)
 };
 
 bool tiled_supports(int N, int M, int D);

@@ -407,6 +407,20 @@ def test_tiled_fused_similarity_and_row_pass(GF, shape, variant):
     assert np.allclose(o.per.cpu().numpy(), ref["per"], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_tiled_dma_contractions_at_ragged_tile_edges(GF, variant):
+    """The 256 x 256 contractions whose operands arrive by buffer_load ... lds (K a multiple of 32, enough tiles to fill the
+    chip): N = 288 (a slot tile of 32 valid columns), N M = 2592 (a row tile of 32 valid rows), D = 320 (a d tile of 64),
+    B = 48 so that k_gc takes the big tile too and cuts its rows into pieces (192 tiles -> 4 pieces).  Sampled batches
+    against the fp64 closed form."""
+    B, N, M, D = 48, 288, 9, 320
+    E = orc.synth_embeddings((B, N, M, D), "raw", seed=77)
+    o = run_hip(GF, E, 7.5, -2.0, variant, "tiled")
+    for i in (0, 23, 47):
+        ref = orc.closed_form(E[i], 7.5, -2.0, variant=variant)
+        check({k: v[i] for k, v in o.items()}, ref, "tiled", f"dma ragged {variant} batch {i}")
+
+
 @pytest.mark.parametrize("shape", [(64, 10, 256), (4, 5, 256), (3, 64, 10, 256)])
 def test_cpp_autograd_node_equals_the_python_one(GF, shape):
     """torch.ops.ge2e_amd.loss (libge2e_torch.so) against functional._GE2ELossFunction: the same two C-ABI calls, so loss

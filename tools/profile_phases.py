@@ -35,6 +35,11 @@ PHASES = {
               "F2 member scalars, KJP(cur)", "-",
               "A1a (-DGE2E_PROF_A1) wait for the rows (= the memory queue) + speaker sum", "A1b centroid, stores, stage",
               "A1c barrier", "A1d k-group form stores", "A1e drain (vmcnt 0)"],
+    # the three contractions of the tiled pipeline (diagnostic slots 0.., 8.., 16..): wave 0's cycles per BATCH, summed over
+    # the batch's tiles (cfg5: 160 similarity tiles, 12 gC tiles, 120 gE tiles per batch)
+    "tiled": ["sim: until the first stage landed", "sim: K loop", "sim: epilogue issued", "sim: stores drained", "sim loop: slice-1 reads + 24 MFMAs issued", "sim loop: own pieces landed", "sim loop: barrier", "sim loop: pieces + slice-0 reads + 24 MFMAs issued",
+              "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: slice-1 reads + 24 MFMAs issued", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: pieces + slice-0 reads + 24 MFMAs issued",
+              "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: slice-1 reads + 24 MFMAs issued", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: pieces + slice-0 reads + 24 MFMAs issued"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -45,9 +50,12 @@ def main():
     ap.add_argument("--impl", default="fused_f32")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batches", type=int, default=1024)
+    ap.add_argument("--no-build", action="store_true", help="use the libge2e_hip_prof.so that is there (built off the GPU box)")
+    ap.add_argument("--lib", default="libge2e_hip_prof.so", help="file name of the stamped library inside the package directory")
     args = ap.parse_args()
-    lib_path = os.path.join(build.PKG_DIR, "libge2e_hip_prof.so")
-    build.build_variant(lib_path, ["-DGE2E_PROFILE"] + os.environ.get("GE2E_EXTRA_DEFS", "").split())
+    lib_path = os.path.join(build.PKG_DIR, args.lib)
+    if not (args.no_build and os.path.exists(lib_path)):
+        build.build_variant(lib_path, ["-DGE2E_PROFILE"] + os.environ.get("GE2E_EXTRA_DEFS", "").split())
     lib = C.CDLL(lib_path)
     for name, (res, argt) in _lib.PROTOTYPES.items():
         getattr(lib, name).restype = res
@@ -92,7 +100,7 @@ def main():
     print(f"{args.impl} {args.config} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
           f"{tot:.0f} cycles per batch per workgroup")
     for i, n in enumerate(names):
-        if cyc[i] > 0:
+        if i < len(cyc) and cyc[i] > 0:
             print(f"  {n:34s} {cyc[i]:10.0f} cyc  {100 * cyc[i] / tot:5.1f} %")
 
 
