@@ -302,16 +302,38 @@ __device__ __forceinline__ h8 dma_frag(const _Float16* pl, int blk, int s, int l
 #else
 #define DMA_STAMP(i)
 #endif
+// A contraction in two calls, so that a workgroup that walks several tiles can ask for the NEXT tile's first two stages
+// before it writes the current tile out (dma_begin ... epilogue ... dma_run): the ~5 k cycles in which a fresh workgroup
+// waits for its first stage, and the launch of a workgroup per tile, go away.
+struct DmaJob {
+    DmaRs rA, rB;
+    unsigned voA[2], voB[2];
+    int nk;
+};
 template <class C, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
-                                              f32x16 (&acc)[C::A2][C::B2], unsigned long long* t_first = nullptr) {
+__device__ __forceinline__ void dma_begin(DmaJob& j, const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid) {
     static_assert(C::TM == 256 && C::TN == 256 && C::KS == 32 && (size_t)2 * DMA_ST * 2 <= C::LDS_BYTES, "big tile only");
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    j.rA = dma_rsrc<C, AKC, C::TM>(A, ktotal);
+    j.rB = dma_rsrc<C, BKC, C::TN>(B, ktotal);
+    dma_piece_offsets<AKC>(A, lane, wid, j.voA);
+    dma_piece_offsets<BKC>(B, lane, wid, j.voB);
+    j.nk = ktotal / 32;
+    const unsigned sm_byte = (unsigned)(unsigned long long)(lds_void_p)sm;
+    dma_issue(j.rA, j.rB, j.voA, j.voB, 0u, 0u, sm_byte, wid);
+    if (j.nk > 1) dma_issue(j.rA, j.rB, j.voA, j.voB, j.rA.kstep_bytes, j.rB.kstep_bytes, sm_byte + 2u * DMA_ST, wid);
+}
+// drain_all: memory instructions younger than the job's pieces may be outstanding (the previous tile's epilogue) -- wait
+// for everything instead of "all but the second stage's eight pieces".
+template <class C, bool AKC, bool BKC>
+__device__ __forceinline__ void dma_run(const DmaJob& j, _Float16* sm, int tid, f32x16 (&acc)[C::A2][C::B2], bool drain_all,
+                                        unsigned long long* t_first = nullptr) {
     const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wa = wid / C::WN, wb = wid % C::WN;
     const int ablk0 = wa * C::A2, bblk0 = wb * C::B2;
-    const DmaRs rA = dma_rsrc<C, AKC, C::TM>(A, ktotal), rB = dma_rsrc<C, BKC, C::TN>(B, ktotal);
-    unsigned voA[2], voB[2];
-    dma_piece_offsets<AKC>(A, lane, wid, voA);
-    dma_piece_offsets<BKC>(B, lane, wid, voB);
+    const DmaRs& rA = j.rA;
+    const DmaRs& rB = j.rB;
+    const unsigned (&voA)[2] = j.voA;
+    const unsigned (&voB)[2] = j.voB;
     const unsigned sm_byte = (unsigned)(unsigned long long)(lds_void_p)sm;
     // Schedule of one K-step k (two 16-wide slices s0, s1; F0 / F1 = the twelve fragments of a slice, 48 VGPRs each):
     //     read F1(k, s1)  |  24 MFMAs on F0(k, s0)      -- the reads return under the MFMAs
@@ -320,16 +342,10 @@ __device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int 
     //     read F0(k + 1, s0)  |  24 MFMAs on F1(k, s1)
     // A piece has a whole K-step (~1.3 us of MFMAs) to land, no fragment read is waited for with the matrix pipe idle, one
     // barrier per K-step.  The sched_barriers pin the order (left alone hipcc moves the barrier up to the first MFMA).
-    const int nk = ktotal / 32;
-    unsigned kA = 0, kB = 0;
-    dma_issue(rA, rB, voA, voB, 0u, 0u, sm_byte, wid);
-    if (nk > 1) {
-        kA = rA.kstep_bytes; kB = rB.kstep_bytes;
-        dma_issue(rA, rB, voA, voB, kA, kB, sm_byte + 2u * DMA_ST, wid);
-        dma_wait_but(8);       // the eight pieces of step 0 (pieces land in issue order)
-    } else {
-        dma_wait();
-    }
+    const int nk = j.nk;
+    unsigned kA = nk > 1 ? rA.kstep_bytes : 0u, kB = nk > 1 ? rB.kstep_bytes : 0u;
+    if (nk > 1 && !drain_all) dma_wait_but(8);       // the eight pieces of step 0 (pieces land in issue order)
+    else dma_wait();
     __syncthreads();
 #ifdef GE2E_PROFILE
     unsigned long long last_ = 0;
@@ -423,6 +439,14 @@ __device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int 
         }
 #endif
     }
+    __builtin_amdgcn_s_setprio(0);
+}
+template <class C, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
+                                              f32x16 (&acc)[C::A2][C::B2], unsigned long long* t_first = nullptr) {
+    DmaJob j;
+    dma_begin<C, AKC, BKC>(j, A, B, ktotal, sm, tid);
+    dma_run<C, AKC, BKC>(j, sm, tid, acc, false, t_first);
 }
 
 // acc[a2][b2] += A[wave rows + 32 a2 ..][K] . B[wave cols + 32 b2 ..][K]  over K = [0, ktotal)
@@ -671,6 +695,45 @@ __device__ __forceinline__ int xcd_major_tile(unsigned b, unsigned grid) {
     return b < per * 8 ? (int)((b % 8) * per + b / 8) : (int)b;
 }
 
+// One workgroup, several tiles (the DMA configuration only; launched with min(tiles, CUs) workgroups): `decode(t, A, B, ix)`
+// sets a tile's operands and indices, `epilogue(ix, acc)` writes it out.  The next tile's first two stages are requested
+// before the current tile's epilogue; virtual workgroup numbers b, b + grid, ... keep a workgroup on one XCD's contiguous
+// range of tiles (xcd_major_tile below; grid is a multiple of 8 or a single pass).
+template <class C, bool AKC, bool BKC, class Ix, class Decode, class Epilogue>
+__device__ __forceinline__ void walk_tiles(int ntiles, int ktotal_unused, _Float16* sm, int tid, Decode decode, Epilogue epilogue,
+                                           unsigned long long* t_first = nullptr) {
+    (void)ktotal_unused;
+    f32x16 acc[C::A2][C::B2];
+    if constexpr (!C::DMA) {    // one tile per workgroup
+        Opnd A, Bo; Ix ix; int ktotal;
+        decode(xcd_major_tile(blockIdx.x, gridDim.x), A, Bo, ix, ktotal);
+        gemm_zero<C>(acc);
+        gemm_tile<C, AKC, BKC>(A, Bo, ktotal, sm, tid, acc);
+        epilogue(ix, acc);
+    } else {
+        int lin = blockIdx.x;
+        Opnd A, Bo; Ix ix; int ktotal;
+        decode(xcd_major_tile(lin, ntiles), A, Bo, ix, ktotal);
+        DmaJob j;
+        dma_begin<C, AKC, BKC>(j, A, Bo, ktotal, sm, tid);
+        bool first = true;
+        for (;;) {
+            gemm_zero<C>(acc);
+            dma_run<C, AKC, BKC>(j, sm, tid, acc, !first, t_first);
+            first = false;
+            const int nlin = lin + (int)gridDim.x;
+            const Ix cur = ix;
+            if (nlin < ntiles) {   // (every wave is past the last barrier of the loop: nobody reads the stages any more)
+                decode(xcd_major_tile(nlin, ntiles), A, Bo, ix, ktotal);
+                dma_begin<C, AKC, BKC>(j, A, Bo, ktotal, sm, tid);
+            }
+            epilogue(cur, acc);
+            if (nlin >= ntiles) break;
+            lin = nlin;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_sim: X[r][k] = sum_d EH[r][d] CH[k][d].  One workgroup per TM x TN tile (both operands K-contiguous).
 template <class C>
@@ -679,48 +742,48 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M;
     const int rt = (NM + C::TM - 1) / C::TM, ct = (N + C::TN - 1) / C::TN;
-    int t = xcd_major_tile(blockIdx.x, gridDim.x);
-    const int kt = t % ct; t /= ct;
-    const int rtile = t % rt;
-    const int bi = t / rt;
     const size_t NMp = (size_t)NM;
-    Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NMp * D + (size_t)rtile * C::TM * D;
-    A.lo = A.hi + NMp * D;
-    A.ld = D; A.valid = min(C::TM, NM - rtile * C::TM);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + (size_t)kt * C::TN * D;
-    Bo.lo = Bo.hi + (size_t)N * D;
-    Bo.ld = D; Bo.valid = min(C::TN, N - kt * C::TN);
-    f32x16 acc[C::A2][C::B2];
-    gemm_zero<C>(acc);
+    struct Ix { int kt, rtile, bi; };
+    auto decode = [&](int t, Opnd& A, Opnd& Bo, Ix& ix, int& ktotal) {
+        ix.kt = t % ct; t /= ct;
+        ix.rtile = t % rt;
+        ix.bi = t / rt;
+        A.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)ix.bi * 2 * NMp * D + (size_t)ix.rtile * C::TM * D;
+        A.lo = A.hi + NMp * D;
+        A.ld = D; A.valid = min(C::TM, NM - ix.rtile * C::TM);
+        Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)ix.bi * 2 * N * D + (size_t)ix.kt * C::TN * D;
+        Bo.lo = Bo.hi + (size_t)N * D;
+        Bo.ld = D; Bo.valid = min(C::TN, N - ix.kt * C::TN);
+        ktotal = D;
+    };
     GE2E_PROF_DECL(8)
     unsigned long long t_first[5] = {0, 0, 0, 0, 0};
-    gemm_tile<C, true, true>(A, Bo, D, gsm, tid, acc, t_first);
-    GE2E_PROF_AT(0, t_first[0]);
-    GE2E_PROF(1);
+    auto epilogue = [&](const Ix& ix, f32x16 (&acc)[C::A2][C::B2]) {
+        GE2E_PROF_AT(0, t_first[0]);
+        GE2E_PROF(1);
+        float* X = p.ws + L.x + (size_t)ix.bi * NMp * L.npad;
+        const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = ix.rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
+#pragma unroll
+                for (int b2 = 0; b2 < C::B2; ++b2) {
+                    float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                    quad_transpose4(x, lane);
+                    const int k = ix.kt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
+                    if (r < NM && k < L.npad)
+                        *reinterpret_cast<float4*>(X + (size_t)r * L.npad + k) =
+                            make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
+                }
+            }
+        GE2E_PROF(2);
+    };
+    walk_tiles<C, true, true, Ix>(p.B * rt * ct, D, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
-    float* X = p.ws + L.x + (size_t)bi * NMp * L.npad;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
-#pragma unroll
-    for (int a2 = 0; a2 < C::A2; ++a2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
-#pragma unroll
-            for (int b2 = 0; b2 < C::B2; ++b2) {
-                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
-                quad_transpose4(x, lane);
-                const int k = kt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
-                if (r < NM && k < L.npad)
-                    *reinterpret_cast<float4*>(X + (size_t)r * L.npad + k) =
-                        make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
-            }
-        }
-    GE2E_PROF(2);
-    GE2E_PROF_DRAIN();
-    GE2E_PROF(3);
     GE2E_PROF_FLUSH_AT(0, 8)
 }
 
@@ -1259,51 +1322,52 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, D = p.D, NM = p.N * p.M, npad = L.npad;
     const int dtiles = (D + C::TN - 1) / C::TN, ct = (N + C::TM - 1) / C::TM;
-    int t = xcd_major_tile(blockIdx.x, gridDim.x);
-    const int dt = t % dtiles; t /= dtiles;
-    const int kt = t % ct; t /= ct;
-    const int S = L.gc_split, sp = t % S;
-    const int bi = t / S;
-    // rows [r0, r1) of the batch: piece sp of S (whole 32-row K-steps when S > 1 -- the launcher splits only then)
-    const int steps = NM / 32;
-    const int r0 = S > 1 ? (int)((long long)steps * sp / S) * 32 : 0, r1 = S > 1 ? (int)((long long)steps * (sp + 1) / S) * 32 : NM;
-    Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)r0 * npad + kt * C::TM;
-    A.lo = A.hi + (size_t)NM * npad;
-    A.ld = npad; A.valid = min(C::TM, npad - kt * C::TM);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)bi * 2 * NM * D + (size_t)r0 * D + dt * C::TN;
-    Bo.lo = Bo.hi + (size_t)NM * D;
-    Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
-    f32x16 acc[C::A2][C::B2];
-    gemm_zero<C>(acc);
+    const int S = L.gc_split, steps = NM / 32;
+    struct Ix { int dt, kt, sp, bi; };
+    auto decode = [&](int t, Opnd& A, Opnd& Bo, Ix& ix, int& ktotal) {
+        ix.dt = t % dtiles; t /= dtiles;
+        ix.kt = t % ct; t /= ct;
+        ix.sp = t % S;
+        ix.bi = t / S;
+        // rows [r0, r1) of the batch: piece sp of S (whole 32-row K-steps when S > 1 -- the launcher splits only then)
+        const int r0 = S > 1 ? (int)((long long)steps * ix.sp / S) * 32 : 0;
+        const int r1 = S > 1 ? (int)((long long)steps * (ix.sp + 1) / S) * 32 : NM;
+        A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)ix.bi * 2 * NM * npad + (size_t)r0 * npad + ix.kt * C::TM;
+        A.lo = A.hi + (size_t)NM * npad;
+        A.ld = npad; A.valid = min(C::TM, npad - ix.kt * C::TM);
+        Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.eh) + (size_t)ix.bi * 2 * NM * D + (size_t)r0 * D + ix.dt * C::TN;
+        Bo.lo = Bo.hi + (size_t)NM * D;
+        Bo.ld = D; Bo.valid = min(C::TN, D - ix.dt * C::TN);
+        ktotal = r1 - r0;
+    };
     GE2E_PROF_DECL(8)
     unsigned long long t_first[5] = {0, 0, 0, 0, 0};
-    gemm_tile<C, false, false>(A, Bo, r1 - r0, gsm, tid, acc, t_first);
-    GE2E_PROF_AT(0, t_first[0]);
-    GE2E_PROF(1);
+    auto epilogue = [&](const Ix& ix, f32x16 (&acc)[C::A2][C::B2]) {
+        GE2E_PROF_AT(0, t_first[0]);
+        GE2E_PROF(1);
+        float* GC = S > 1 ? p.ws + L.x + ((size_t)ix.bi * S + ix.sp) * N * D : p.ws + L.gc + (size_t)ix.bi * N * D;
+        const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k = ix.kt * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
+#pragma unroll
+                for (int b2 = 0; b2 < C::B2; ++b2) {
+                    float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                    quad_transpose4(x, lane);
+                    const int d = ix.dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
+                    if (k < N && d < D)
+                        *reinterpret_cast<float4*>(GC + (size_t)k * D + d) =
+                            make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
+                }
+            }
+        GE2E_PROF(2);
+    };
+    walk_tiles<C, false, false, Ix>(p.B * S * ct * dtiles, NM, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
-    float* GC = S > 1 ? p.ws + L.x + ((size_t)bi * S + sp) * N * D : p.ws + L.gc + (size_t)bi * N * D;
-    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
-#pragma unroll
-    for (int a2 = 0; a2 < C::A2; ++a2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int k = kt * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
-#pragma unroll
-            for (int b2 = 0; b2 < C::B2; ++b2) {
-                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
-                quad_transpose4(x, lane);
-                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
-                if (k < N && d < D)
-                    *reinterpret_cast<float4*>(GC + (size_t)k * D + d) =
-                        make_float4(x[0] * kSplitInv2, x[1] * kSplitInv2, x[2] * kSplitInv2, x[3] * kSplitInv2);
-            }
-        }
-    GE2E_PROF(2);
-    GE2E_PROF_DRAIN();
-    GE2E_PROF(3);
     GE2E_PROF_FLUSH_AT(8, 8)
 }
 
@@ -1382,74 +1446,75 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int N = p.N, M = p.M, D = p.D, NM = N * M, npad = L.npad;
     const int dtiles = (D + C::TN - 1) / C::TN, rt = (NM + C::TM - 1) / C::TM;
-    int t = xcd_major_tile(blockIdx.x, gridDim.x);
-    const int dt = t % dtiles; t /= dtiles;
-    const int rtile = t % rt;
-    const int bi = t / rt;
-    Opnd A, Bo;
-    A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NM * npad + (size_t)rtile * C::TM * npad;
-    A.lo = A.hi + (size_t)NM * npad;
-    A.ld = npad; A.valid = min(C::TM, NM - rtile * C::TM);
-    Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)bi * 2 * N * D + dt * C::TN;
-    Bo.lo = Bo.hi + (size_t)N * D;
-    Bo.ld = D; Bo.valid = min(C::TN, D - dt * C::TN);
-    f32x16 acc[C::A2][C::B2];
-    gemm_zero<C>(acc);
+    struct Ix { int dt, rtile, bi; };
+    auto decode = [&](int t, Opnd& A, Opnd& Bo, Ix& ix, int& ktotal) {
+        ix.dt = t % dtiles; t /= dtiles;
+        ix.rtile = t % rt;
+        ix.bi = t / rt;
+        A.hi = reinterpret_cast<const _Float16*>(p.ws + L.gh) + (size_t)ix.bi * 2 * NM * npad + (size_t)ix.rtile * C::TM * npad;
+        A.lo = A.hi + (size_t)NM * npad;
+        A.ld = npad; A.valid = min(C::TM, NM - ix.rtile * C::TM);
+        Bo.hi = reinterpret_cast<const _Float16*>(p.ws + L.ch) + (size_t)ix.bi * 2 * N * D + ix.dt * C::TN;
+        Bo.lo = Bo.hi + (size_t)N * D;
+        Bo.ld = D; Bo.valid = min(C::TN, D - ix.dt * C::TN);
+        ktotal = N;      // K = the N real centroid slots (pad columns of GH are zero)
+    };
     GE2E_PROF_DECL(8)
     unsigned long long t_first[5] = {0, 0, 0, 0, 0};
-    gemm_tile<C, true, false>(A, Bo, N, gsm, tid, acc, t_first);   // K = the N real centroid slots (pad columns of GH are zero)
-    GE2E_PROF_AT(0, t_first[0]);
-    GE2E_PROF(1);
+    auto epilogue = [&](const Ix& ix, f32x16 (&acc)[C::A2][C::B2]) {
+        GE2E_PROF_AT(0, t_first[0]);
+        GE2E_PROF(1);
+        const int rtile = ix.rtile, dt = ix.dt;
+        const float* E = p.E + (size_t)ix.bi * NM * D;
+        float* dE = p.dE + (size_t)ix.bi * NM * D;
+        const float* KJ = p.ws + L.kj + (size_t)ix.bi * N * D;
+        const float* RS = p.ws + L.rs + (size_t)ix.bi * NM * 8;
+        // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
+        // columns: every global access of the epilogue is 16 bytes wide (8 rows x 128 B per wave-instruction)
+        const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
+        // The loads of a 32-row block (4 row scalars, 8 x 16 B of e, 8 x 16 B of KJ per lane: 72 VGPRs, free now that the
+        // fragments are dead) are all requested before the first is used, on clamped addresses so that no branch separates
+        // them: one memory round trip per block instead of one per 16 bytes (stamped build, config 5, round 4: the epilogue
+        // was 35 % of the workgroup's time at 12 GB/s per CU -- latency, not bandwidth).
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2) {
+            float2 rs[4];
+            float4 e[4][C::B2], kj[4][C::B2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
+                const int rc = r < NM ? r : NM - 1;
+                rs[g] = *reinterpret_cast<const float2*>(RS + (size_t)rc * 8);  // ra c1e
+                const int j = rc / M;
+#pragma unroll
+                for (int b2 = 0; b2 < C::B2; ++b2) {
+                    const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
+                    const int dc = d < D ? d : 0;
+                    e[g][b2] = *reinterpret_cast<const float4*>(E + (size_t)rc * D + dc);
+                    kj[g][b2] = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + dc);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
+#pragma unroll
+                for (int b2 = 0; b2 < C::B2; ++b2) {
+                    float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
+                    quad_transpose4(x, lane);
+                    const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
+                    if (r < NM && d < D)
+                        *reinterpret_cast<float4*>(dE + (size_t)r * D + d) =
+                            make_float4(x[0] * rs[g].x + e[g][b2].x * rs[g].y + kj[g][b2].x, x[1] * rs[g].x + e[g][b2].y * rs[g].y + kj[g][b2].y,
+                                        x[2] * rs[g].x + e[g][b2].z * rs[g].y + kj[g][b2].z, x[3] * rs[g].x + e[g][b2].w * rs[g].y + kj[g][b2].w);
+                }
+            }
+        }
+        GE2E_PROF(2);
+    };
+    walk_tiles<C, true, false, Ix>(p.B * rt * dtiles, N, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
-    const float* E = p.E + (size_t)bi * NM * D;
-    float* dE = p.dE + (size_t)bi * NM * D;
-    const float* KJ = p.ws + L.kj + (size_t)bi * N * D;
-    const float* RS = p.ws + L.rs + (size_t)bi * NM * 8;
-    // in-quad transposes turn four accumulator registers (4 rows x this lane's column) into one row x 4 consecutive
-    // columns: every global access of the epilogue is 16 bytes wide (8 rows x 128 B per wave-instruction)
-    const int l31 = lane & 31, h = lane >> 5, wa = wid / C::WN, wb = wid % C::WN, pq = lane & 3, cq = l31 >> 2;
-    // The loads of a 32-row block (4 row scalars, 8 x 16 B of e, 8 x 16 B of KJ per lane: 72 VGPRs, free now that the
-    // fragments are dead) are all requested before the first is used, on clamped addresses so that no branch separates
-    // them: one memory round trip per block instead of one per 16 bytes (stamped build, config 5, round 4: the epilogue
-    // was 35 % of the workgroup's time at 12 GB/s per CU -- latency, not bandwidth).
-#pragma unroll
-    for (int a2 = 0; a2 < C::A2; ++a2) {
-        float2 rs[4];
-        float4 e[4][C::B2], kj[4][C::B2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
-            const int rc = r < NM ? r : NM - 1;
-            rs[g] = *reinterpret_cast<const float2*>(RS + (size_t)rc * 8);  // ra c1e
-            const int j = rc / M;
-#pragma unroll
-            for (int b2 = 0; b2 < C::B2; ++b2) {
-                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
-                const int dc = d < D ? d : 0;
-                e[g][b2] = *reinterpret_cast<const float4*>(E + (size_t)rc * D + dc);
-                kj[g][b2] = *reinterpret_cast<const float4*>(KJ + (size_t)j * D + dc);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = rtile * C::TM + wa * (32 * C::A2) + 32 * a2 + 8 * g + 4 * h + pq;
-#pragma unroll
-            for (int b2 = 0; b2 < C::B2; ++b2) {
-                float x[4] = {acc[a2][b2][4 * g], acc[a2][b2][4 * g + 1], acc[a2][b2][4 * g + 2], acc[a2][b2][4 * g + 3]};
-                quad_transpose4(x, lane);
-                const int d = dt * C::TN + wb * (32 * C::B2) + 32 * b2 + 4 * cq;
-                if (r < NM && d < D)
-                    *reinterpret_cast<float4*>(dE + (size_t)r * D + d) =
-                        make_float4(x[0] * rs[g].x + e[g][b2].x * rs[g].y + kj[g][b2].x, x[1] * rs[g].x + e[g][b2].y * rs[g].y + kj[g][b2].y,
-                                    x[2] * rs[g].x + e[g][b2].z * rs[g].y + kj[g][b2].z, x[3] * rs[g].x + e[g][b2].w * rs[g].y + kj[g][b2].w);
-            }
-        }
-    }
-    GE2E_PROF(2);
-    GE2E_PROF_DRAIN();
-    GE2E_PROF(3);
     GE2E_PROF_FLUSH_AT(16, 8)
 }
 
@@ -1554,6 +1619,11 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
         }
     }
     auto tiles = [](int n, int t) { return (unsigned)((n + t - 1) / t); };
+    // the DMA-fed contractions walk their tiles with one workgroup per CU (160 KB of LDS: one fits)
+    int ncu = device_cu_count();
+    if (ncu < 8) ncu = 8;
+    ncu = ncu / 8 * 8;    // a workgroup's tiles b, b + grid, ... stay on one XCD when the grid is a multiple of 8
+    auto walk_grid = [&](unsigned ntiles) { return dim3(ntiles < (unsigned)ncu ? ntiles : (unsigned)ncu); };
     // the 256 x 256 tile where both extents of the contraction's output reach it AND its grid still gives every CU
     // most of the CUs a workgroup (a single batch of cfg5 has 160 big tiles), else 128 x 128
     const unsigned fill = 192;   // (measured: the long-K gC contraction gains from the big tile even at one workgroup per CU)
@@ -1584,7 +1654,7 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
             else hipLaunchKernelGGL((ge2e_tiled_simrows<C3, false, false>), g, dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         }
     } else if (big_sim && p.D % 32 == 0)
-        hipLaunchKernelGGL(ge2e_tiled_sim<C3>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+        hipLaunchKernelGGL(ge2e_tiled_sim<C3>, walk_grid((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else
@@ -1596,14 +1666,14 @@ hipError_t launch_tiled(const Problem& p, hipStream_t stream) {
         hipLaunchKernelGGL(ge2e_tiled_rows, dim3(row_blocks), dim3(256), 0, stream, p, L);
     if (p.dE) {
         if (big_gc && NM % 32 == 0)
-            hipLaunchKernelGGL(ge2e_tiled_gc<C3>, dim3((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) * L.gc_split), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            hipLaunchKernelGGL(ge2e_tiled_gc<C3>, walk_grid((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256) * L.gc_split), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else if (big_gc)
             hipLaunchKernelGGL(ge2e_tiled_gc<C2>, dim3((unsigned)p.B * tiles(p.N, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else
             hipLaunchKernelGGL(ge2e_tiled_gc<C1>, dim3((unsigned)p.B * tiles(p.N, 128) * tiles(p.D, 128)), dim3(C1::NT), C1::LDS_BYTES, stream, p, L);
         hipLaunchKernelGGL(ge2e_tiled_spk, dim3(spk_blocks), dim3(256), 0, stream, p, L);
         if (big_ge && p.N % 32 == 0)
-            hipLaunchKernelGGL(ge2e_tiled_ge<C3>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+            hipLaunchKernelGGL(ge2e_tiled_ge<C3>, walk_grid((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else if (big_ge)
             hipLaunchKernelGGL(ge2e_tiled_ge<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.D, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
         else
@@ -1630,7 +1700,11 @@ hipError_t launch_tiled_cos(const Problem& p, hipStream_t stream) {
     const bool big_sim = NM >= 256 && p.N >= 256 && (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256) >= 192;
     launch_prep(p, L, stream);
     if (big_sim && p.D % 32 == 0)
-        hipLaunchKernelGGL(ge2e_tiled_sim<GemmCfgDma>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    {   // (one workgroup per CU walks the tiles: see launch_tiled)
+        const int ncu = device_cu_count() < 8 ? 8 : device_cu_count();
+        const unsigned nt = (unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256), cap = (unsigned)(ncu / 8 * 8);
+        hipLaunchKernelGGL(ge2e_tiled_sim<GemmCfgDma>, dim3(nt < cap ? nt : cap), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
+    }
     else if (big_sim)
         hipLaunchKernelGGL(ge2e_tiled_sim<C2>, dim3((unsigned)p.B * tiles(NM, 256) * tiles(p.N, 256)), dim3(C2::NT), C2::LDS_BYTES, stream, p, L);
     else

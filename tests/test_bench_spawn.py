@@ -41,7 +41,7 @@ def test_gpus_8_cfg4_train_step_dry_run():
 
 def test_gpus_1_stays_one_process():
     j = run("--gpus", "1")
-    assert j["n_gpus"] == 1 and j["config"]["batches_per_launch"] == 4096 and j["config"]["mode"] == "loss"
+    assert j["n_gpus"] == 1 and j["config"]["batches_per_launch"] == 16384 and j["config"]["mode"] == "loss"
     assert j["rccl_ranks"] == 1 and len(j["per_rank_value"]) == 1
 
 

@@ -132,13 +132,22 @@ def test_config5_large(GF):
 
 
 def test_config5_benched_launch_sampled(GF):
-    """cfg5 at the launch size bench.py times (B = 16): sampled batches against the fp64 closed form."""
-    B, N, M, D = 16, 1024, 10, 768
-    E = orc.synth_embeddings((B, N, M, D), "unit", seed=11)
-    o = run_hip(GF, E, 10.0, -5.0, impl="auto")
-    for i in (0, 7, 15):
-        ref = orc.closed_form(E[i], 10.0, -5.0)
-        check({k: v[i] for k, v in o.items()}, ref, "auto", f"cfg5 B=16 batch {i}", strict=True)
+    """cfg5 at the launch size bench.py times (bench.CONFIGS["cfg5"]["B"] batches, generated on the device): sampled
+    batches against the fp64 closed form."""
+    import bench
+    B, N, M, D = bench.CONFIGS["cfg5"]["B"], 1024, 10, 768
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    e = torch.nn.functional.normalize(torch.randn(B, N, M, D, generator=g, device=dev), dim=-1)
+    nan = lambda *s: torch.full(s, float("nan"), device=dev)  # noqa: E731
+    out = GF.LossOutputs(loss=nan(B), per=nan(B, N, M), dE=nan(B, N, M, D), dw=nan(B), db=nan(B))
+    o = GF.loss_fwd_bwd(e, torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev), impl="auto", out=out)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.loss).all()) and bool(torch.isfinite(o.dE).all())
+    for i in (0, B // 2 - 1, B - 1):
+        ref = orc.closed_form(e[i].cpu().numpy(), 10.0, -5.0)
+        check({k: getattr(o, k)[i].cpu().numpy() for k in ("loss", "per", "dE", "dw", "db")}, ref, "auto", f"cfg5 B={B} batch {i}",
+              strict=True)
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 2, 1), (1, 2, 2, 3), (3, 5, 3, 7), (2, 7, 4, 65), (1, 65, 2, 33),
@@ -386,6 +395,22 @@ def test_cos_sim_on_the_matrix_cores(GF, shape):
         t = torch.as_tensor(E[bi])
         ref = orc.expand_form_cos_sim(t, orc.centroids(t)).numpy()
         assert np.abs(cos[bi].cpu().numpy() - ref).max() < 5e-6
+
+
+def test_cos_sim_through_the_walked_dma_tiles(GF):
+    """ge2e_cos_sim at a shape whose similarity contraction takes the DMA-fed 256 x 256 tile with one workgroup per CU
+    walking the tiles (24 x 11 x 2 = 528 tiles for 256 workgroups; ragged row, slot and K edges as in the loss test)."""
+    B, N, M, D = 24, 288, 9, 320
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    e = torch.nn.functional.normalize(torch.randn(B, N, M, D, generator=g, device=dev), dim=-1)
+    cos = GF.cos_sim(e)
+    ref_valu = GF.cos_sim(e, GF.centroids(e))
+    torch.cuda.synchronize()
+    assert cos.shape == (B, N, M, N) and bool(torch.isfinite(cos).all())
+    assert float((cos - ref_valu).abs().max()) < 5e-6
+    t = e[B - 1].cpu()
+    assert np.abs(cos[B - 1].cpu().numpy() - orc.expand_form_cos_sim(t, orc.centroids(t)).numpy()).max() < 5e-6
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 10, 256), (2, 200, 4, 64), (2, 129, 7, 128), (1, 256, 2, 64), (2, 255, 3, 192)])

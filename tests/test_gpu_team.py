@@ -8,6 +8,9 @@ import torch
 from conftest import rel_fro
 from oracle import ge2e_oracle as orc
 from test_gpu_parity import run_hip
+import bench
+
+BENCH_B = bench.CONFIGS["cfg2"]["B"]      # batches per launch of the metric config's bench line
 
 pytestmark = pytest.mark.gpu
 
@@ -196,10 +199,10 @@ def _check_sampled(e, o, picks, w=10.0, b=-5.0):
 
 @pytest.mark.parametrize("impl", ("team", "auto"))
 def test_benched_launch_size(GF, impl):
-    """The launch bench.py times: B = 4096 at the metric shape, 128 pipelined batches per team.  Every output finite,
-    sampled batches (first, last, team boundaries, the middle, a few random ones) against the fp64 oracle, and the
-    whole launch against the one-workgroup-per-batch kernel."""
-    B, N, M, D = 4096, 64, 10, 256
+    """The launch bench.py times: bench.CONFIGS["cfg2"]["B"] batches at the metric shape (64 pipelined batches per team).
+    Every output finite, sampled batches (first, last, team boundaries, the middle, a few random ones) against the fp64
+    oracle, and the whole launch against the one-workgroup-per-batch kernel."""
+    B, N, M, D = BENCH_B, 64, 10, 256
     e = _device_batches(B, N, M, D, 77)
     w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
     nan = lambda *s: torch.full(s, float("nan"), device="cuda:0")  # noqa: E731
@@ -209,21 +212,24 @@ def test_benched_launch_size(GF, impl):
     assert bool(torch.isfinite(o.loss).all()) and bool(torch.isfinite(o.dw).all()) and bool(torch.isfinite(o.db).all())
     assert bool(torch.isfinite(o.dE).all())
     rng = np.random.default_rng(5)
-    _check_sampled(e, o, [0, 31, 32, 255, 256, 2047, 2048, 4064, 4095] + [int(x) for x in rng.integers(0, B, 4)])
+    _check_sampled(e, o, [0, 31, 32, 255, 256, B // 2 - 1, B // 2, B - 32, B - 1] + [int(x) for x in rng.integers(0, B, 4)])
     of = GF.loss_fwd_bwd(e, w, b, impl="fused_split")
     torch.cuda.synchronize()
     assert torch.allclose(o.loss, of.loss, rtol=2e-6)
     assert torch.allclose(o.dw, of.dw, rtol=2e-5, atol=1e-6) and torch.allclose(o.db, of.db, atol=2e-5)
-    num = (o.dE - of.dE).flatten(1).norm(dim=1)
-    den = of.dE.flatten(1).norm(dim=1)
-    assert float((num / den).max()) < 5e-6
+    worst = 0.0
+    for c0 in range(0, B, 2048):     # in pieces: the difference of two 10 GB tensors need not exist at once
+        num = (o.dE[c0:c0 + 2048] - of.dE[c0:c0 + 2048]).flatten(1).norm(dim=1)
+        den = of.dE[c0:c0 + 2048].flatten(1).norm(dim=1)
+        worst = max(worst, float((num / den).max()))
+    assert worst < 5e-6
 
 
 @pytest.mark.parametrize("impl", ("team", "auto"))
 def test_forward_only_at_the_benched_launch_size(GF, impl):
-    """bench.py's forward_only leg: B = 4096 at the metric shape with dE = NULL (similarity + loss, s4:61-110 /
+    """bench.py's forward_only leg: the benched batch count at the metric shape with dE = NULL (similarity + loss, s4:61-110 /
     s5:42-44).  loss and per-row losses: all finite, equal to the fwd+bwd launch's, sampled batches against the oracle."""
-    B, N, M, D = 4096, 64, 10, 256
+    B, N, M, D = BENCH_B, 64, 10, 256
     e = _device_batches(B, N, M, D, 78)
     w, b = torch.tensor(10.0, device="cuda:0"), torch.tensor(-5.0, device="cuda:0")
     nan = lambda *s: torch.full(s, float("nan"), device="cuda:0")  # noqa: E731
@@ -235,7 +241,7 @@ def test_forward_only_at_the_benched_launch_size(GF, impl):
     # the forward-only launch is an instantiation of its own (no gradient code compiled in): same arithmetic, but the
     # compiler may contract an fma differently -- last-bit agreement, not bitwise
     assert torch.allclose(of.loss, og.loss, rtol=1e-6) and torch.allclose(of.per, og.per, rtol=2e-6, atol=2e-6)
-    for i in (0, 31, 32, 2048, 4095):
+    for i in (0, 31, 32, B // 2, B - 1):
         ref = orc.closed_form(e[i].cpu().numpy(), 10.0, -5.0, want_grad=False)
         assert abs(float(of.loss[i]) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), i
         assert np.abs(of.per[i].cpu().numpy() - ref["per"]).max() <= 2e-5 * max(1.0, np.abs(ref["per"]).max()), i
