@@ -1,21 +1,29 @@
 // GE2E_IMPL_TILED: shapes whose centroids do not fit one workgroup's LDS (N > 64 or D > 256:
-// BASELINE configs 4 and 5).  Many workgroups per batch, six small kernels on one stream, the
-// three contractions as 64 x 64 x 64 LDS-tiled split-fp16 MFMA GEMMs (ge2e_split_gemm.hpp) over
-// operand images that are split ONCE into fp16 hi / lo planes in the workspace:
+// BASELINE configs 4 and 5).  Many workgroups per batch, five or six kernels on one stream, the
+// three contractions on one split-fp16 MFMA tile core (below) over operand images that are split
+// ONCE into fp16 hi / lo planes in the workspace:
 //
 //   k_prep    per speaker : sums, c-hat -> CH images + fp32 copy; per row: 1/|e|, e-hat -> EH images
-//   k_sim     X = EH . CH^T                    tiles (64 rows x 64 centroids), K = D      (s3:64-70)
+//   k_sim     X = EH . CH^T                    tiles (rows x centroids), K = D                    (s3:64-70)
 //   k_rows    per row     : leave-one-out cosine from X's own column, S, loss, dL/dS -> GH images (the own-speaker
 //                           column carries the coefficient of s_j), row coefficients of the gradient  (s3:27, 115-127)
-//   k_gc      gC = GH^T . EH                   tiles (64 centroids x 64 d), K = all N*M rows
+//   k_simrows = k_sim + k_rows in one kernel where a 256-slot tile holds a whole similarity row (128 < N <= 256): X never
+//               goes to memory
+//   k_gc      gC = GH^T . EH                   tiles (centroids x d), K = all N*M rows (cut into pieces where that fills
+//                                              the chip; k_spk adds the partial sums)
 //   k_spk     per speaker : gC through the centroid norm + a multiple of c-hat_j -> KJ rows (the leave-one-out speaker row
-//                           sum_i c3_i e-hat_i is already in gC_j through GH's own column: no second pass over the rows)
+//                           sum_i c3_i e-hat_i is already in gC_j through GH's own column: no second pass over the rows);
+//                           the batch's loss / dw / db sums
 //   k_ge      gE = GH . CH, epilogue dE = ra gE + c1e e + KJ_j
-//   k_reduce  loss / dw / db: fixed-order sum of the per-row values
+//   k_reduce  loss / dw / db of forward-only calls
+//
+// Tile core: 128 x 128 x 64 on four waves (one LDS stage + register prefetch, two workgroups per CU), 256 x 256 x 32 on
+// eight waves with two LDS stages -- register-staged (gemm_tile) or, when K is a multiple of 32, fed by
+// buffer_load ... lds with one workgroup per CU walking its tiles (gemm_tile_dma / walk_tiles, GemmCfgDma).
 //
 // Shapes: D % 64 == 0, D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
-// Same algebra and same split arithmetic as ge2e_fused_split.hip; config 5 is MFMA-bound
-// (SURVEY 8d), so the extra image traffic (L2 / Infinity-Cache resident) is not the limiter.
+// Same algebra and same split arithmetic as ge2e_fused_split.hip.  Config 5 is bound by the contractions, config
+// 4 by the bytes the pipeline moves.
 #include "ge2e_common.hpp"
 #include "ge2e_split_gemm.hpp"
 #include "ge2e_tiled.hpp"
@@ -700,9 +708,8 @@ __device__ __forceinline__ int xcd_major_tile(unsigned b, unsigned grid) {
 // before the current tile's epilogue; virtual workgroup numbers b, b + grid, ... keep a workgroup on one XCD's contiguous
 // range of tiles (xcd_major_tile below; grid is a multiple of 8 or a single pass).
 template <class C, bool AKC, bool BKC, class Ix, class Decode, class Epilogue>
-__device__ __forceinline__ void walk_tiles(int ntiles, int ktotal_unused, _Float16* sm, int tid, Decode decode, Epilogue epilogue,
+__device__ __forceinline__ void walk_tiles(int ntiles, _Float16* sm, int tid, Decode decode, Epilogue epilogue,
                                            unsigned long long* t_first = nullptr) {
-    (void)ktotal_unused;
     f32x16 acc[C::A2][C::B2];
     if constexpr (!C::DMA) {    // one tile per workgroup
         Opnd A, Bo; Ix ix; int ktotal;
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_sim(Problem p, TiledWs L)
             }
         GE2E_PROF(2);
     };
-    walk_tiles<C, true, true, Ix>(p.B * rt * ct, D, gsm, tid, decode, epilogue, t_first);
+    walk_tiles<C, true, true, Ix>(p.B * rt * ct, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
@@ -1364,7 +1371,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_gc(Problem p, TiledWs L) 
             }
         GE2E_PROF(2);
     };
-    walk_tiles<C, false, false, Ix>(p.B * S * ct * dtiles, NM, gsm, tid, decode, epilogue, t_first);
+    walk_tiles<C, false, false, Ix>(p.B * S * ct * dtiles, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
@@ -1511,7 +1518,7 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_ge(Problem p, TiledWs L) 
         }
         GE2E_PROF(2);
     };
-    walk_tiles<C, true, false, Ix>(p.B * rt * dtiles, N, gsm, tid, decode, epilogue, t_first);
+    walk_tiles<C, true, false, Ix>(p.B * rt * dtiles, gsm, tid, decode, epilogue, t_first);
 #ifdef GE2E_PROFILE
     for (int i = 0; i < 4; ++i) prof_acc[4 + i] = t_first[1 + i];
 #endif
