@@ -9,19 +9,24 @@ from speaker_embedding_ge2e_loss_amd import functional as GF
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 bad = 0
-shapes = [(4096, 64, 10, 256), (150, 64, 10, 256), (9, 64, 10, 256), (33, 23, 7, 128), (40, 64, 10, 64), (17, 40, 16, 64), (300, 32, 16, 192), (700, 4, 5, 256), (90, 2, 16, 256),
+shapes = [(16384, 64, 10, 256), (4096, 64, 10, 256), (150, 64, 10, 256), (9, 64, 10, 256), (33, 23, 7, 128), (40, 64, 10, 64), (17, 40, 16, 64), (300, 32, 16, 192), (700, 4, 5, 256), (90, 2, 16, 256),
           # TILED: fused similarity + row pass and the DMA-fed contractions (cfg4), k_gc cut along its rows (cfg5), ragged tile edges
           (256, 256, 10, 256), (16, 1024, 10, 768), (48, 288, 9, 320)]
 for (B, N, M, D) in shapes:
-    E = orc.synth_embeddings((B, N, M, D), "unit", seed=B)
-    ref = orc.closed_form(E[:4], 10.0, -5.0)
-    e = torch.as_tensor(E, device=dev)
+    if B > 5000:     # the bench's launch size: generated on the device (a 10 GB stack is slow to make on the host)
+        g = torch.Generator(device=dev).manual_seed(B)
+        e = torch.nn.functional.normalize(torch.randn(B, N, M, D, generator=g, device=dev), dim=-1)
+        ref = orc.closed_form(e[:4].cpu().numpy(), 10.0, -5.0)
+    else:
+        E = orc.synth_embeddings((B, N, M, D), "unit", seed=B)
+        ref = orc.closed_form(E[:4], 10.0, -5.0)
+        e = torch.as_tensor(E, device=dev)
     w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
     impl = GF.resolve_impl(B, N, M, D, "softmax", "auto")
     out = GF.LossOutputs(loss=torch.empty(B, device=dev), per=None, dE=torch.empty_like(e), dw=torch.empty(B, device=dev), db=torch.empty(B, device=dev))
     ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", impl), dev)
     first = None
-    reps = 60 if B > 1000 else 40 if N >= 256 else 300
+    reps = 20 if B > 10000 else 60 if B > 1000 else 40 if N >= 256 else 300
     for k in range(reps):
         out.dE.fill_(float("nan")); out.loss.fill_(float("nan"))
         GF.loss_fwd_bwd(e, w, b, impl=impl, out=out, workspace=ws)
