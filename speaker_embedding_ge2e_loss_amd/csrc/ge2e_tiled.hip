@@ -943,14 +943,14 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
     for (int b2 = 0; b2 < C::B2; ++b2) {
         float z = 0.f, a = 0.f;
         if (!CONTRAST) {
-            const float tb = bs - mx[b2];
+            const float tb2 = (bs - mx[b2]) * 1.44269504088896341f, ws2 = ws * 1.44269504088896341f;   // base 2: one instruction per exponential
 #pragma unroll
             for (int a2 = 0; a2 < C::A2; ++a2)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int c = 32 * a2 + 8 * (v >> 2) + (v & 3);
                     const float x = acc[a2][b2][v];
-                    float g = __expf(fmaf(ws, x, tb));
+                    float g = __builtin_amdgcn_exp2f(fmaf(ws2, x, tb2));
                     g = ((FULL || c < nq) && c != jq[b2]) ? g : 0.f;
                     z += g;
                     a = fmaf(g, x, a);
@@ -1032,13 +1032,29 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
             if (p.per) p.per[gr] = per;
         }
     }
+    if (!p.dE) return;      // forward-only calls: nobody reads the dL/dS planes (a third of this kernel's time and 2.7 MB per tile)
     __syncthreads();        // XCH has been read: the region below it is about to hold the G tile
 
     // ---- dL/dS -> split fp16 -> LDS tile [row][slot] -> the GH planes as whole rows, one plane at a time ------------
     _Float16* const GHh = reinterpret_cast<_Float16*>(p.ws + L.gh) + (size_t)bi * 2 * NMp * npad + (size_t)rtile * C::TN * npad;
     const int rows_here = min(C::TN, NM - rtile * C::TN);
-#pragma unroll 1
-    for (int plane = 0; plane < 2; ++plane) {
+    // The tile is formed ONCE: the hi halves go to the LDS tile, the lo halves are parked in the accumulator registers they
+    // came from (two registers per four values) until the hi plane has left.  (Round 4's first form ran the select, the scale
+    // and the whole split once per plane: ~1 000 of the kernel's 4 100 vector instructions per wave.)
+    auto write_plane = [&](int plane) {
+        __syncthreads();
+        _Float16* const G = GHh + (size_t)plane * NMp * npad;
+        for (int idx = tid; idx < 256 * 32; idx += C::NT) {          // 32 16-byte pieces per row
+            const int row = idx >> 5, c8 = (idx & 31) * 8;
+            if (row < rows_here && c8 < npad) {
+                const uint2 lo8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8);
+                const uint2 hi8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8 + 4);
+                *reinterpret_cast<uint4*>(G + (size_t)row * npad + c8) = make_uint4(lo8.x, lo8.y, hi8.x, hi8.y);
+            }
+        }
+        __syncthreads();
+    };
+    {
         GE2E_SR_OPAQUE();
         (void)nq;
 #pragma unroll
@@ -1056,21 +1072,25 @@ __global__ __launch_bounds__(C::NT, 2) void ge2e_tiled_simrows(Problem p, TiledW
                     }
                     h4 hi, lo;
                     split4(make_float4(gv[0], gv[1], gv[2], gv[3]), hi, lo);
-                    *reinterpret_cast<h4*>(TT + rloc * TTP + soff + 32 * a2 + 8 * vg) = plane == 0 ? hi : lo;
+                    *reinterpret_cast<h4*>(TT + rloc * TTP + soff + 32 * a2 + 8 * vg) = hi;
+                    const uint2 lb = __builtin_bit_cast(uint2, lo);
+                    acc[a2][b2][4 * vg] = __uint_as_float(lb.x);
+                    acc[a2][b2][4 * vg + 1] = __uint_as_float(lb.y);
                 }
         }
-        __syncthreads();
-        _Float16* const G = GHh + (size_t)plane * NMp * npad;
-        for (int idx = tid; idx < 256 * 32; idx += C::NT) {          // 32 16-byte pieces per row
-            const int row = idx >> 5, c8 = (idx & 31) * 8;
-            if (row < rows_here && c8 < npad) {
-                const uint2 lo8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8);
-                const uint2 hi8 = *reinterpret_cast<const uint2*>(TT + row * TTP + c8 + 4);
-                *reinterpret_cast<uint4*>(G + (size_t)row * npad + c8) = make_uint4(lo8.x, lo8.y, hi8.x, hi8.y);
-            }
-        }
-        __syncthreads();
     }
+    write_plane(0);
+#pragma unroll
+    for (int b2 = 0; b2 < C::B2; ++b2) {
+        const int rloc = 64 * wb + 32 * b2 + l31;
+#pragma unroll
+        for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+            for (int vg = 0; vg < 4; ++vg)
+                *reinterpret_cast<uint2*>(TT + rloc * TTP + soff + 32 * a2 + 8 * vg) =
+                    make_uint2(__float_as_uint(acc[a2][b2][4 * vg]), __float_as_uint(acc[a2][b2][4 * vg + 1]));
+    }
+    write_plane(1);
 #undef GE2E_SR_OPAQUE
 }
 
@@ -1174,10 +1194,12 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows(Problem p, TiledWs L) {
                 // leave-one-out speaker row sum_i c3_i e-hat_i minus kap_j (sum_i c3_i xo_i) c-hat_j (ge2e_team.hip, S)
                 if (k == j) { ad = gv[e]; gv[e] = own_o * gv[e]; }
             }
-            h4 hi, lo;
-            split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
-            *reinterpret_cast<h4*>(GHh + kb) = hi;
-            *reinterpret_cast<h4*>(GHl + kb) = lo;
+            if (p.dE) {      // (forward-only calls: nobody reads the dL/dS planes)
+                h4 hi, lo;
+                split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
+                *reinterpret_cast<h4*>(GHh + kb) = hi;
+                *reinterpret_cast<h4*>(GHl + kb) = lo;
+            }
         }
     }
     dwv = wave_sum(dwv); dbv = wave_sum(dbv);
@@ -1298,7 +1320,7 @@ __global__ __launch_bounds__(256) void ge2e_tiled_rows16(Problem p, TiledWs L) {
             }
             h4 hi, lo;
             split4(make_float4(gv[0] * kSplitScale, gv[1] * kSplitScale, gv[2] * kSplitScale, gv[3] * kSplitScale), hi, lo);
-            if (live) {
+            if (live && p.dE) {      // (forward-only calls: nobody reads the dL/dS planes)
                 *reinterpret_cast<h4*>(GHh + kb) = hi;
                 *reinterpret_cast<h4*>(GHl + kb) = lo;
             }
