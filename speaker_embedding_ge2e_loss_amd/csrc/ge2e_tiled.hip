@@ -1436,9 +1436,11 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
     }
     coef = wave_sum(coef);
     const float f = cs.y * coef, sc = cs.x / fM;
+    // sum_i c4'_i: the whole speaker row KJP_j is a multiple of c-hat_j (the e-hat part rides in gC).  Lane i reads row i's
+    // coefficient and the wave adds them (as a loop over i this was M dependent round trips per wave: a run-time M is not unrolled)
     float bsum = 0.f;
-    for (int i = 0; i < M; ++i) bsum += RS[i * 8 + 4];
-    const float bs = bsum;      // sum_i c4'_i: the whole speaker row KJP_j is a multiple of c-hat_j (the e-hat part rides in gC)
+    for (int i = lane; i < M; i += kWave) bsum += RS[i * 8 + 4];
+    const float bs = wave_sum(bsum);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d = 256 * q + 4 * lane;
@@ -1453,6 +1455,7 @@ __global__ __launch_bounds__(256) void ge2e_tiled_spk(Problem p, TiledWs L) {
     if (j == 0) {
         const float* RSb = p.ws + L.rs + (size_t)bi * NM * 8;
         float red[3] = {0.f, 0.f, 0.f};
+#pragma unroll 8     // (eight loads in flight: this wave has NM / 64 of them in a row while its 4 N - 1 siblings have one round trip)
         for (int r = lane; r < NM; r += kWave) {
             const float4 v = *reinterpret_cast<const float4*>(RSb + (size_t)r * 8 + 4);   // . loss dw db
             red[0] += v.y; red[1] += v.z; red[2] += v.w;
