@@ -53,9 +53,7 @@ constexpr unsigned OOB = 0x7FFFFF00u;
 constexpr int AUX_L2 = 16;    // sc1: served by L2, never by this CU's L1 (hand-off reads)
 constexpr int AUX_NT = 2;
 #ifndef GE2E_T2_DE_AUX
-#define GE2E_T2_DE_AUX 16     // cache policy of the dE stores: sc1.  Swept again at 16 384 batches per launch (same box, interleaved,
-                              // twice): default 2.24, nt 2.27, sc1 2.30, sc0 sc1 2.29, sc1 nt 2.26, sc0 sc1 nt 2.26 M batches/s
-                              // (rounds 2-4, 4 096 batches per launch: nt, no difference to sc1)
+#define GE2E_T2_DE_AUX 2      // cache policy of the dE stores (tools/bench_variants.py sweeps it)
 #endif
 // column tile i of this wave in GE / dE.  Two tiles per wave (D > 128): ADJACENT tiles, so that after the half-row
 // exchange at the end of GE a lane pair-of-tiles covers whole 128-byte lines of dE (see T2_PAIR_LINES)
