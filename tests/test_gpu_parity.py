@@ -397,6 +397,16 @@ def test_cos_sim_on_the_matrix_cores(GF, shape):
         assert np.abs(cos[bi].cpu().numpy() - ref).max() < 5e-6
 
 
+@pytest.mark.parametrize("variant", ["softmax", "contrast"])
+def test_tiled_more_than_64_utterances_per_speaker(GF, variant):
+    """M = 70: a speaker's rows outnumber the lanes of the wave that sums their coefficients in k_spk (the lane loop wraps);
+    against the fp64 closed form."""
+    B, N, M, D = 3, 130, 70, 128
+    E = orc.synth_embeddings((B, N, M, D), "unit", seed=70)
+    ref = orc.closed_form(E, 9.0, -4.0, variant=variant)
+    check(run_hip(GF, E, 9.0, -4.0, variant, "tiled"), ref, "tiled", f"M=70 {variant}")
+
+
 def test_cos_sim_through_the_walked_dma_tiles(GF):
     """ge2e_cos_sim at a shape whose similarity contraction takes the DMA-fed 256 x 256 tile with one workgroup per CU
     walking the tiles (24 x 11 x 2 = 528 tiles for 256 workgroups; ragged row, slot and K edges as in the loss test)."""
