@@ -78,11 +78,18 @@ def spawn_ranks(n):
 
 
 def synth(B, N, M, D, seed, device):
-    """normalize(randn) rows = the encoder's output contract (s2:34); generated on the host."""
-    g = torch.Generator().manual_seed(seed)
-    e = torch.randn(B, N, M, D, generator=g, dtype=torch.float32)
-    e = torch.nn.functional.normalize(e, dim=-1)
-    return e.to(device)
+    """normalize(randn) rows = the encoder's output contract (s2:34).  Generated ON THE DEVICE, in place and in slabs (rounds
+    1-4 built the 10.7 GB block and its normalised copy on the host: 25 s of a 30 s run, and eight times that side by side
+    under --gpus 8).  The post-timing `verify` pulls the sampled batches of THIS data back and hands them to the oracle."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    e = torch.empty(B, N, M, D, dtype=torch.float32, device=dev)
+    slab = max(1, (1 << 28) // (N * M * D))           # 1 GiB of fp32 per slab
+    for i in range(0, B, slab):
+        part = e[i:i + slab]
+        part.normal_(generator=g)
+        part.div_(part.norm(dim=-1, keepdim=True).clamp_min_(1e-12))
+    return e
 
 
 def cpu_baseline(N, M, D, variant, budget_s=12.0):
@@ -389,6 +396,8 @@ def main():
                          if fwd_mfma else
                          {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}),
             "algorithmic_bytes_per_launch": fb * B, "algorithmic_flops_per_launch": ff * B,
+            "traffic": (measured_traffic(args.config, impl + "_fwd", B) or {}).get("bytes"),
+            "traffic_from_profile": measured_traffic(args.config, impl + "_fwd", B),
             "verify": None if args.no_verify else verify_forward(E, out_f.loss, out_f.per, N, M, D, variant)}
     if rank == 0 and not dry and args.mode == "loss" and not args.no_extras and not args.forward_only:
         # B = 1 latency, raw C-ABI call (not the metric; launch-bound single batches)
@@ -527,7 +536,7 @@ def main():
                 common["note"] = "launch time here includes the bucket all-reduce (train-step mode)"
             # HBM-side bytes of this launch: not measurable in-process -- taken from the committed rocprofv3 PMC passes of
             # the same command, only while the kernel sources still hash to what was profiled (else null)
-            tp = measured_traffic(args.config, impl, B)
+            tp = measured_traffic(args.config, impl + ("_fwd" if args.forward_only else ""), B)
             if mfma_bound:
                 roof = {"bound": "mfma", "achieved": issued_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                         "frac": issued_tf / MFMA_F16_PEAK_TF, "traffic": (tp or {}).get("bytes"), "traffic_from_profile": tp,

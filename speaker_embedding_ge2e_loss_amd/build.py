@@ -56,7 +56,7 @@ def is_stale() -> bool:
 # Per-source compile flags.  ge2e_team.hip: no SLP vectorisation -- hipcc packs the fp32 epilogue arithmetic that
 # follows its (inline-asm) MFMA chains into v_pk_mul_f32 / v_pk_fma_f32, and on gfx950 those lost the fused-in term in
 # the low register of a pair, lanes 48..63, in up to 70 % of the launches (hazards).
-EXTRA_FLAGS = {"ge2e_team.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"ge2e_team.hip": ["-fno-slp-vectorize"], "ge2e_team_fwd.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
 
 

@@ -1,0 +1,515 @@
+// GE2E_IMPL_TEAM, FORWARD ONLY (dE == NULL): similarity + loss -- the launch of the reference's evaluation paths (s4:61-110 test
+// loss, s5:42-44) and the workload north_star's roofline sentence names.  A kernel of its own, not the training pipeline
+// with the gradient phases compiled out (rounds 3-4): that one left a forward batch as ONE serial chain per workgroup --
+// speaker sums -> publish -> hand-off -> images -> contraction -> softmax, five workgroup barriers, nothing else resident on
+// the CU to fill the waits (14.5 k cycles per batch for ~6 k cycles of issue).
+//
+// Same team as ge2e_team.hip (eight workgroups on eight CUs of one XCD share a batch, E is read from HBM once, member m
+// owns speaker slots 8 m .. and their rows), same exchange area and control block.  What differs is the schedule: TWO
+// batches are in flight per workgroup and every long latency has most of an iteration to travel.
+//
+//   iteration n (cur = batch n of this team, prev = n - 1):
+//     A1(cur)   wave s = speaker slot s: sum of its M rows (registers RA, requested two iterations ago) -> unit centroid ->
+//               published as MFMA fragments (fragment-major, ge2e_team.hip)
+//     X(prev)   X[slot][row] of prev on 16x16x32 split-fp16 MFMA: centroid fragments of prev in registers (requested at
+//               the end of the previous iteration), the member's e-hat images in LDS; wave (slot tile, K half) -> XB0 / XB1
+//     --        drain, BARRIER 1, one lane signals c1: cur's centroids are published (and prev's scalars, below)
+//     A2(cur)   wave s: |e| of its rows (one reduce-scatter), e-hat -> split-fp16 images (overwrites prev's: X(prev) is done)
+//     rows      RA <- RB (batch n + 1, requested an iteration ago); rows of batch n + 2 requested into RB
+//     S(prev)   wave = speaker, 4 lanes per row, 16 similarities per lane from XB0 + XB1: leave-one-out cosine on the own
+//               column, softmax / contrast, per-row loss -> loss, (dw, db) partials
+//     W         one lane polls c1 for cur (signalled a phase and a half ago); BARRIER 2
+//     requests  centroid fragments of cur from L2 -> registers; member scalars of prev -> exchange; member 0 sums the eight
+//               members' scalars of batch n - 2 (made visible by this iteration's hand-off) -> loss / dw / db
+//   Two workgroup barriers per batch.  HBM latency has the whole iteration (rows), the hand-off has A2 + S, the L2 round
+//   trip of the fragments has A1.  After the last batch two extra signals carry the last two batches' scalars to member 0.
+//
+// LDS per member: e-hat hi / lo images 80 KB + X halves 43.5 KB + row scalars (double-buffered) 5 KB: one workgroup per CU.
+// Exchange per batch and team: 64 KB of centroid fragments (double-buffered by parity) + 128 bytes of scalars.
+#include "ge2e_common.hpp"
+#include "ge2e_split_gemm.hpp"
+#include "ge2e_team.hpp"
+#include "ge2e_team_kernel.hpp"
+#include "ge2e_team_dev.hpp"
+
+namespace ge2e {
+
+// LDS of the forward-only kernel for `rt` image rows
+size_t team_fwd_lds_bytes(int rt, int D) {
+    return (size_t)2 * rt * D * 2 + (size_t)2 * rt * XP * 4 + (size_t)(2 * rt * 4 + 32 + 16) * sizeof(float);
+}
+
+template <int NCH, int MR, int RBT, bool CONTRAST>
+__global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKWs L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int D = 64 * NCH;
+    constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
+    constexpr unsigned ROWB = D * 4;
+    constexpr TeamKX XO = team_exchange(D);
+    constexpr unsigned SC4 = XO.cst[0];   // member scalars [4 batches in flight][8 members][4 floats]: the region the training
+                                          // kernel uses for slot scalars (2 KB), which the forward pass keeps in registers
+    constexpr int RBC = RBT ? RBT : RBMAX;
+    const int RB = RBT ? RBT : L.rt / 16;
+    const int RT = 16 * RB;
+    const int RBr = RB;
+    constexpr bool CT_X = RBT != 0;
+    _Float16* const ETh = reinterpret_cast<_Float16*>(smem_f);
+    _Float16* const ETl = ETh + RT * P;
+    float* const XB0 = reinterpret_cast<float*>(ETl + RT * P);
+    float* const XB1 = XB0 + RT * XP;
+    float* const RS = XB1 + RT * XP;                               // [2][RT][4]  1/|e|c, kappa, |e|^2, |e|c  (by batch parity)
+    float* const RED = RS + 2 * RT * 4;                            // [32]
+    int* const SH = reinterpret_cast<int*>(RED + 32);              // [16]
+
+    constexpr bool MEX = RBT != 0;        // the metric shape: N = 64, M = MR, every member full
+    const int N = MEX ? 64 : p.N, M = MEX ? MR : p.M, NM = N * M;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
+    TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
+    const TeamId id = team_form(ctl, SH);
+    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the gated launch takes over
+        __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (id.team < 0) return;
+    TeamKFlags* const fl = flags + id.team;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
+        reinterpret_cast<const char*>(p.ws) + L.head_bytes + (size_t)id.team * XO.stride, XO.stride);
+
+    const int spm = MEX ? 8 : L.spm;
+    const int w_bits = __builtin_amdgcn_readfirstlane(__float_as_int(p.w ? *p.w : p.w_imm));
+    const int b_bits = __builtin_amdgcn_readfirstlane(__float_as_int(p.b ? *p.b : p.b_imm));
+    const float eps = p.eps, eps_cos = p.eps_cos;
+#define GE2E_TF_CONSTS()                                                                       \
+    int wb_ = w_bits, bb_ = b_bits, mc_ = M, le_ = __float_as_int(p.log_eps);                  \
+    asm volatile("" : "+s"(wb_), "+s"(bb_), "+s"(mc_), "+s"(le_));                             \
+    const float w = __int_as_float(wb_), bias = __int_as_float(bb_);                           \
+    const float eps_cos2 = eps_cos * eps_cos;                                                  \
+    const float fM = (float)mc_, inv_m = rcp_nr(fM), inv_m1 = rcp_nr((float)(mc_ - 1));       \
+    (void)w; (void)bias; (void)eps_cos2; (void)fM; (void)inv_m; (void)inv_m1; (void)le_
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+    // rows of the images that never receive an embedding stay zero (finite similarities for the padded rows)
+    for (int i = tid; i < RT * P / 8; i += 512) {
+        reinterpret_cast<float4*>(ETh)[i] = zero4();
+        reinterpret_cast<float4*>(ETl)[i] = zero4();
+    }
+    for (int i = tid; i < 2 * RT; i += 512) reinterpret_cast<float4*>(RS)[i] = zero4();
+    __syncthreads();
+
+    float4 ra[MR], rb2[MR];     // this wave's rows: RA = the batch about to start, RB = the one after it (in flight)
+    h8 xa[NCH][2];              // centroid fragments of the batch X works on: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..
+    float sn_cur = 0.f, ss_cur = 0.f, sn_prev = 0.f, ss_prev = 0.f;   // |s_j| (clamped), |s_j|^2 of this wave's speaker
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) { xa[s][0] = h8{}; xa[s][1] = h8{}; }
+
+    // every load unconditional: a disabled one gets an out-of-bounds offset (the buffer resource returns zeros)
+#define GE2E_TF_LOAD_ROWS(REG, BI)                                                                       \
+    do {                                                                                                 \
+        int lq_ = lane;                                                                                  \
+        asm volatile("" : "+v"(lq_));                                                                    \
+        const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                  \
+        const bool on_ = has_spk && (BI) < p.B;                                                          \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
+            REG[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+    } while (0)
+#define GE2E_TF_LANE()                                                  \
+    int lv_ = lane;                                                     \
+    asm volatile("" : "+v"(lv_));                                       \
+    const int l15 = lv_ & 15, q = lv_ >> 4, d4 = 4 * lv_;               \
+    const bool dact = D == 256 || d4 < D;                               \
+    (void)l15; (void)q; (void)d4; (void)dact
+
+    GE2E_PROF_DECL(20)
+    {
+        const int j0 = id.member * spm;
+        const int my_spm = MEX ? 8 : max(0, min(spm, N - j0));
+        const bool has_spk = wid < my_spm;
+        const int j = j0 + wid;
+        GE2E_TF_LOAD_ROWS(ra, id.team);
+        GE2E_TF_LOAD_ROWS(rb2, id.team + id.nct);
+    }
+    const TeamId id_outer = id;
+    bool failed = false;
+    int nsig = 0;                       // signals this member has given (every member gives the same number)
+    const int wid_outer = wid, member_outer = id.member, tid_outer = tid, m_outer = M;
+    for (int seq = 0;; ++seq) {
+        // wave- and member-derived scalars are re-derived in every iteration from opaque copies (ge2e_team.hip, hazard 8)
+        int wid_o = wid_outer, mem_o = member_outer, tid_o = tid_outer, m_o = m_outer;
+        asm volatile("" : "+s"(wid_o), "+s"(mem_o), "+v"(tid_o), "+s"(m_o));
+        const int wid = wid_o, tid = tid_o, lane = tid & 63, M = MEX ? MR : m_o, NM = N * M;
+        TeamId id = id_outer;
+        id.member = mem_o;
+        const int j0 = id.member * spm;
+        const int my_spm = MEX ? 8 : max(0, min(spm, N - j0));
+        const bool has_spk = wid < my_spm;
+        const int j = j0 + wid;
+        const int kslot = 8 * id.member + wid;             // the slot this wave is responsible for
+        const int rbase = wid * M;                         // first row of that speaker in the images
+        const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
+        const int bi = id.team + seq * id.nct;             // batch started in this iteration
+        const bool have_cur = bi < p.B, have_prev = seq > 0;
+        if (!have_cur && !have_prev) break;
+        const int buf = seq & 1, pbuf = buf ^ 1;
+        sn_prev = sn_cur; ss_prev = ss_cur;
+
+        // ===== A1(cur): speaker sum -> unit centroid -> published (fragment-major) ==================================
+        if (have_cur) {
+            GE2E_TF_LANE();
+            GE2E_TF_CONSTS();
+            float4 s = zero4();
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M) { s.x += ra[i].x; s.y += ra[i].y; s.z += ra[i].z; s.w += ra[i].w; }
+            const float4 c = scale4(s, inv_m);
+            float sqs[2] = {dot4(c, c), dot4(s, s)};
+            wave_sum_to_sgpr<2>(sqs);
+            float rn, kap, nc;
+            unit_stats_bf(sqs[0], eps_cos, eps_cos2, rn, kap, nc);
+            if (!has_spk) { rn = 0.f; nc = 0.f; }              // slots without a speaker publish zero rows
+            sn_cur = has_spk ? fM * nc : 0.f;
+            ss_cur = has_spk ? sqs[1] : 0.f;
+            h4 hi, lo;
+            split4(scale4(c, rn * kSplitScale), hi, lo);
+            // one 1-KB block per (slot tile, hi / lo, 32-column K-step) holding the 64 lanes' 16-byte MFMA fragments in lane
+            // order (lane = 16 q + slot-in-tile): a consumer's load instruction reads 1 KB contiguously
+            const unsigned blk = (unsigned)(kslot >> 4) * (4u * NCH) + (unsigned)(lv_ >> 3);
+            const unsigned vh = dact ? blk * 1024u + (unsigned)(((lv_ >> 1) & 3) * 16 + (kslot & 15)) * 16u + (unsigned)(lv_ & 1) * 8u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + XO.chr[buf], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, 0);
+        }
+        GE2E_PROF(0);
+
+        // ===== X(prev): X[slot][r] over this wave's K half -> LDS (fragments of the next K-step under the MFMAs) ======
+        if (have_prev) {
+            GE2E_TF_LANE();
+            float* const XBk = khX ? XB1 : XB0;
+            const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
+            h8 fb[2][2];
+            f32x4 acc[2] = {acc_zero4(), acc_zero4()};
+#define TF_X_LOAD(T_)                                                                                     \
+    do {                                                                                                  \
+        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
+        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
+        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
+    } while (0)
+#define TF_X_STORE(RB_)                                                                       \
+    *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
+        make_float4(acc[(RB_) & 1][0], acc[(RB_) & 1][1], acc[(RB_) & 1][2], acc[(RB_) & 1][3])
+            TF_X_LOAD(0);
+#pragma unroll
+            for (int rb = 0; rb < RBC; ++rb) {
+                if (CT_X || rb < RBr) {
+                    acc[rb & 1] = acc_zero4();
+#pragma unroll
+                    for (int s = 0; s < NCH; ++s) {
+                        const int t = rb * NCH + s;
+                        if (t + 1 < RBC * NCH && (CT_X || t + 1 < RBr * NCH)) TF_X_LOAD(t + 1);
+                        mfma16x3(acc[rb & 1], xa[s][0], xa[s][1], fb[t & 1][0], fb[t & 1][1]);
+                        __builtin_amdgcn_sched_barrier(0);   // fragments at most one K-step ahead (registers)
+                    }
+                    if (rb > 0) { TF_X_STORE(rb - 1); }
+                }
+            }
+            if (CT_X) { TF_X_STORE(RBT - 1); }
+            else {
+#pragma unroll
+                for (int rb = 0; rb < RBC; ++rb)
+                    if (rb == RBr - 1) { TF_X_STORE(rb); }
+            }
+#undef TF_X_LOAD
+#undef TF_X_STORE
+        }
+        GE2E_PROF(1);
+
+        // ---- drain + BARRIER 1: cur's centroid is in L2 (and the member scalars of prev - 1); X(prev) is in LDS and the
+        //      images are free.  Signalled in EVERY iteration: the one behind the last batch carries scalars only.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GE2E_PROF(2);
+        __syncthreads();
+        if (tid == 0) add_agent(&fl->c1, 1u);
+        ++nsig;
+        GE2E_PROF(3);
+
+        // ===== A2(cur): own rows -> |e|, e-hat -> images ============================================================
+        if (have_cur && has_spk) {
+            GE2E_TF_LANE();
+            GE2E_TF_CONSTS();
+            float eev[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(ra[i], ra[i]) : 0.f;
+            const float ee_l = wave_sums_scatter<MR>(eev, lv_);      // row i's |e|^2 in lane scatter_lane(i)
+            float rne_l, ke_l, ne_l;
+            unit_stats_bf(ee_l, eps_cos, eps_cos2, rne_l, ke_l, ne_l);
+            {
+                const int rho = lv_ >> 4, irow = 4 * (lv_ & 15) + (((rho & 1) << 1) | (rho >> 1));
+                if ((lv_ & 15) < (MR + 3) / 4 && irow < M)
+                    *reinterpret_cast<float4*>(RS + (buf * RT + rbase + irow) * 4) = make_float4(rne_l, ke_l, ee_l, ne_l);
+            }
+            const float rs_l = rne_l * kSplitScale;
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                if (i < M) {
+                    const float sc = lane_get(rs_l, scatter_lane(i));
+                    if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(ra[i], sc));
+                }
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
+            }
+        }
+        // ---- RA <- RB (requested an iteration ago), batch n + 2 requested into RB: it has until the next-but-one A1
+#pragma unroll
+        for (int i = 0; i < MR; ++i) ra[i] = rb2[i];
+        GE2E_TF_LOAD_ROWS(rb2, bi + 2 * id.nct);
+        GE2E_PROF(4);
+
+        // ===== S(prev): leave-one-out statistics, softmax / contrast, per-row loss ==================================
+        // Wave s = speaker slot s: FOUR lanes per row, 16 similarities per lane.  Lane (rr = lane >> 2, qq = lane & 3) holds
+        // the slots (sb + j) & 63, j = 0..15, sb = (own slot & ~3) + 16 qq: aligned groups of four, and the own-speaker
+        // column is always one of values 0..3 of the lane qq == 0.
+        float loss_acc = 0.f, dw_acc = 0.f, db_acc = 0.f;
+        if (have_prev && has_spk) {
+            GE2E_TF_LANE();
+            GE2E_TF_CONSTS();
+            const float w2 = w * LOG2E, b2 = (w * eps + bias) * LOG2E, leps2 = __int_as_float(le_) * LOG2E;   // softmax in base 2
+            const int rr = lv_ >> 2, qq = lv_ & 3;
+            const bool rv = rr < M;
+            const int r = rbase + min(rr, M - 1);
+            const int ko = kslot;
+            const int sb = (ko & ~3) + 16 * qq;
+            const int jo = ko & 3;
+            const bool own_lane = qq == 0;
+            const bool all_valid = N == NC;
+            const bool want_wb = p.dw != nullptr || p.db != nullptr;
+            float x[16];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int s4 = (sb + 4 * jj) & (NC - 1);
+                const float4 a = *reinterpret_cast<const float4*>(XB0 + r * XP + s4);
+                const float4 b = *reinterpret_cast<const float4*>(XB1 + r * XP + s4);
+                x[4 * jj + 0] = a.x + b.x; x[4 * jj + 1] = a.y + b.y; x[4 * jj + 2] = a.z + b.z; x[4 * jj + 3] = a.w + b.w;
+            }
+            const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
+            const float4 rs0 = *reinterpret_cast<const float4*>(RS + (pbuf * RT + r) * 4);    // rne ke ee |e|
+            const float rne = rs0.x, ee = rs0.z, ne = rs0.w;
+            const float es = xo * sn_prev * ne;              // e . s_j
+            const float eu = (es - ee) * inv_m1;
+            const float uu = fmaxf((ss_prev - 2.0f * es + ee) * (inv_m1 * inv_m1), 0.0f);
+            float rnu, ku, nu;
+            unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
+            const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+            const float sjj2 = fmaf(w2, cosd, b2);
+            const float w2s = w2 * kSplitInv2;               // S2 = w2s x + b2 on the raw accumulator sums
+            auto vld = [&](int jx) {
+                const int s = (sb + jx) & (NC - 1);
+                return all_valid || (s & 7) < max(0, min(spm, N - (s >> 3) * spm));
+            };
+            bool ownj[4];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) ownj[jx] = own_lane && jo == jx;
+            float per, coefsum = 0.f, db_row = 0.f;
+            if (!CONTRAST) {
+                float xm0 = ownj[0] ? x[1] : x[0], xm1 = ownj[1] ? x[0] : x[1], xm2 = ownj[2] ? x[3] : x[2], xm3 = ownj[3] ? x[2] : x[3];
+                float xm;
+                if (w2 >= 0.f) {
+                    xm = fmaxf(fmaxf(xm0, xm1), fmaxf(xm2, xm3));
+#pragma unroll
+                    for (int jx = 4; jx < 16; jx += 2) xm = fmaxf(fmaxf(x[jx], x[jx + 1]), xm);
+                } else {
+                    xm = fminf(fminf(xm0, xm1), fminf(xm2, xm3));
+#pragma unroll
+                    for (int jx = 4; jx < 16; jx += 2) xm = fminf(fminf(x[jx], x[jx + 1]), xm);
+                }
+                float mx = quad_max(fmaf(w2s, xm, b2));
+                mx = fmaxf(fmaxf(mx, sjj2), leps2);
+                const float t = b2 - mx;
+                float gv[16];
+#pragma unroll
+                for (int jx = 0; jx < 16; ++jx) gv[jx] = __builtin_amdgcn_exp2f(fmaf(w2s, x[jx], t));
+                if (!all_valid) {
+#pragma unroll
+                    for (int jx = 0; jx < 16; ++jx) gv[jx] = vld(jx) ? gv[jx] : 0.f;
+                }
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) gv[jx] = ownj[jx] ? 0.f : gv[jx];
+                float zl = 0.f, al = 0.f;
+#pragma unroll
+                for (int jx = 0; jx < 16; ++jx) zl += gv[jx];
+                if (want_wb) {
+#pragma unroll
+                    for (int jx = 0; jx < 16; ++jx) al = fmaf(gv[jx], x[jx], al);
+                }
+                const float zp = quad_sum(zl);                // sum over the other speakers, shifted
+                const float zoff = zp + __builtin_amdgcn_exp2f(leps2 - mx);
+                const float z = zoff + __builtin_amdgcn_exp2f(sjj2 - mx);
+                per = LN2 * ((mx - sjj2) + __builtin_amdgcn_logf(z));
+                if (want_wb) {
+                    const float ap = quad_sum(al);
+                    const float rz = rcp_nr(z);
+                    const float ad0 = -zoff * rz;             // dL/dS on the own-speaker column: -(1 - p_jj)
+                    coefsum = fmaf(ap * kSplitInv2, rz, ad0 * cosd);     // sum_k dL/dS_k c0_k
+                    db_row = fmaf(zp, rz, ad0);
+                }
+            } else {
+                float best = -INFINITY, bx = 0.f; int besti = 0x7fffffff;
+#pragma unroll
+                for (int jx = 0; jx < 16; ++jx) {
+                    const int s = (sb + jx) & (NC - 1);
+                    const bool ok = vld(jx) && !(jx < 4 && ownj[jx & 3]);
+                    const float sve = ok ? fmaf(w2s, x[jx], b2) : -INFINITY;
+                    if (ok && (sve > best || (sve == best && s < besti))) { best = sve; besti = s; bx = x[jx]; }
+                }
+                const int loci = besti;
+                quad_argmax(best, besti);
+                bx = quad_sum(loci == besti && besti != 0x7fffffff ? bx : 0.f);
+                const float pos = rcp_nr(1.0f + __builtin_amdgcn_exp2f(-sjj2));
+                const float neg = (N > 1) ? rcp_nr(1.0f + __builtin_amdgcn_exp2f(-best)) : 0.0f;
+                per = 1.0f - pos + neg;
+                const float ad0 = -pos * (1.0f - pos);
+                const float gn = neg * (1.0f - neg);
+                coefsum = fmaf(gn, bx * kSplitInv2, ad0 * cosd);
+                db_row = gn + ad0;
+            }
+            if (rv && own_lane) {
+                loss_acc = per;
+                dw_acc = fmaf(eps, db_row, coefsum);
+                db_acc = db_row;
+                if (p.per) p.per[(size_t)(bi - id.nct) * NM + j0 * M + rbase + rr] = per;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
+        if (have_prev) {
+            float v3[3] = {loss_acc, dw_acc, db_acc};
+            wave_sum_to_sgpr<3>(v3);
+            if (lane == 0) { RED[wid] = v3[0]; RED[8 + wid] = v3[1]; RED[16 + wid] = v3[2]; }
+        }
+        GE2E_PROF(5);
+
+        // ===== W: cur's centroids of all members (signalled at barrier 1); BARRIER 2 ================================
+        {
+            int* const wsh = SH + 4 + (seq & 3);
+            if (tid == 0) *wsh = spin_until(&fl->c1, (unsigned)(TEAM * nsig), ctl) ? 1 : 0;
+            __syncthreads();                 // also: the images, row scalars and RED are written; XB has been read
+            if (*wsh == 0) { failed = true; break; }
+        }
+        GE2E_PROF(6);
+
+        // ===== requests: cur's centroid fragments -> registers (used by X in the next iteration) =====================
+        {
+            GE2E_TF_LANE();
+            const unsigned oa = have_cur ? XO.chr[buf] + ((unsigned)tX * (4u * NCH) + (unsigned)khX * NCH) * 1024u + (unsigned)lv_ * 16u : OOB;
+#pragma unroll
+            for (int s = 0; s < NCH; ++s) {
+                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 1024u * s, 0);
+                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 1024u * s + 2048u * NCH, 0);
+            }
+        }
+        // ---- member scalars of prev -> exchange (visible to member 0 after the NEXT signal); member 0: batch n - 2 out
+        if (have_prev && tid == 0) {
+            float l = 0.f, a = 0.f, c = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
+            bstore4(rsX, SC4 + (unsigned)((seq - 1) & 3) * 128u + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
+        }
+        if (seq >= 2 && id.member == 0 && wid == 0) {
+            GE2E_TF_LANE();
+            const float4 scv = bload4<AUX_L2>(rsX, lv_ < TEAM ? SC4 + (unsigned)((seq - 2) & 3) * 128u + (unsigned)lv_ * 16u : OOB, 0);
+            const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+            if (lane == 0) {
+                const int bo = bi - 2 * id.nct;
+                if (p.loss) p.loss[bo] = l;
+                if (p.dw) p.dw[bo] = a;
+                if (p.db) p.db[bo] = c;
+            }
+        }
+        GE2E_PROF(7);
+        if (!have_cur) break;            // that was the iteration behind the last batch
+    }
+    // ---- tail: the scalars of the last two batches.  The loop ended with iteration L (= this team's batch count): batch
+    // L - 2 went to the exchange in iteration L - 1 and was covered by iteration L's signal; batch L - 1 went out just now.
+    if (!failed) {
+        int mem_o = member_outer, tid_o = tid_outer;
+        asm volatile("" : "+s"(mem_o), "+v"(tid_o));
+        const int tid = tid_o, lane = tid & 63;
+        const int nb = id.team < p.B ? (p.B - id.team + id.nct - 1) / id.nct : 0;    // batches of this team = L
+        if (nb > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) add_agent(&fl->c1, 1u);
+            ++nsig;
+            if (mem_o == 0 && tid < 64) {
+                int okv = 1;
+                if (lane == 0) okv = spin_until(&fl->c1, (unsigned)(TEAM * nsig), ctl) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(okv) != 0) {
+                    // iteration L read batch L - 2 (seq >= 2); a team with ONE batch has not read anything yet
+                    const int first = nb >= 2 ? nb - 1 : 0;
+                    for (int k = first; k < nb; ++k) {
+                        const float4 scv = bload4<AUX_L2>(rsX, lane < TEAM ? SC4 + (unsigned)(k & 3) * 128u + (unsigned)lane * 16u : OOB, 0);
+                        const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
+                        if (lane == 0) {
+                            const int bo = id.team + k * id.nct;
+                            if (p.loss) p.loss[bo] = l;
+                            if (p.dw) p.dw[bo] = a;
+                            if (p.db) p.db[bo] = c;
+                        }
+                    }
+                } else {
+                    failed = true;
+                }
+            }
+        }
+    }
+    if (failed && (threadIdx.x & 63) == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GE2E_PROF_FLUSH(20)
+#undef GE2E_TF_LOAD_ROWS
+#undef GE2E_TF_LANE
+#undef GE2E_TF_CONSTS
+}
+
+template <int NCH, int MR, int RBT, bool CONTRAST>
+static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>);
+    static KernelLaunchState state;
+    const unsigned lds = (unsigned)team_fwd_lds_bytes(L.rt, 64 * NCH);
+    int nb = 0;
+    hipError_t err = prepare_kernel(state, fn, 512, lds, &nb);
+    if (err != hipSuccess) return err;
+    if (p.test_abort) {
+        err = launch_team_head_init(p.ws, L.head_bytes, true, stream);
+        if (err != hipSuccess) return err;
+    }
+    int grid = team_grid(p.B);
+    if (p.grid_cap > 0 && p.grid_cap < grid)
+        grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;
+    if (nb < 1 || grid > nb * device_cu_count()) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), lds, stream, p, L);
+    return hipGetLastError();
+}
+template <int NCH, int MR>
+static hipError_t launch_fwd_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64)     // the metric shape: compile-time N, M, trip counts
+        return p.variant == 1 ? launch_fwd_nch<4, 10, 5, true>(p, L, stream) : launch_fwd_nch<4, 10, 5, false>(p, L, stream);
+    return p.variant == 1 ? launch_fwd_nch<NCH, MR, 0, true>(p, L, stream) : launch_fwd_nch<NCH, MR, 0, false>(p, L, stream);
+}
+
+// the team launch of a forward-only call (p.dE == NULL); the caller (launch_team) queues the gated fall-back behind it
+hipError_t launch_team_fwd(Problem& p, TeamKWs& L, hipStream_t stream) {
+    if (p.M <= 10) {
+        switch (p.D / 64) {
+            case 1: return launch_fwd_variant<1, 10>(p, L, stream);
+            case 2: return launch_fwd_variant<2, 10>(p, L, stream);
+            case 3: return launch_fwd_variant<3, 10>(p, L, stream);
+            default: return launch_fwd_variant<4, 10>(p, L, stream);
+        }
+    }
+    switch (p.D / 64) {
+        case 1: return launch_fwd_variant<1, 16>(p, L, stream);
+        case 2: return launch_fwd_variant<2, 16>(p, L, stream);
+        case 3: return launch_fwd_variant<3, 16>(p, L, stream);
+        default: return launch_fwd_variant<4, 16>(p, L, stream);
+    }
+}
+
+}  // namespace ge2e

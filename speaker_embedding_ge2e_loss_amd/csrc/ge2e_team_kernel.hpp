@@ -52,5 +52,8 @@ TeamKWs team_layout(int N, int M, int D);
 int team_grid(int B);
 size_t team_workspace_bytes(int B, int N, int M, int D);
 hipError_t launch_team(const Problem& p, hipStream_t stream);
+// forward-only calls (p.dE == NULL): the team launch alone, ge2e_team_fwd.hip; launch_team queues the gated fall-back behind it
+hipError_t launch_team_fwd(Problem& p, TeamKWs& L, hipStream_t stream);
+size_t team_fwd_lds_bytes(int rt, int D);
 
 }  // namespace ge2e

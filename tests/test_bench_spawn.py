@@ -39,6 +39,30 @@ def test_gpus_8_cfg4_train_step_dry_run():
     assert j["train_step"]["allreduce_busbw_GBs"] > 0
 
 
+def test_gpus_8_cfg2_loss_mode_dry_run():
+    """The driver's scaling command (`--gpus 8`, default mode and config = the metric line) with eight ranks on CPU: the
+    line names cfg2's workload, weak scaling over whole batches, eight ranks counted by a real collective."""
+    j = run("--gpus", "8", "--config", "cfg2")
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and len(j["per_rank_value"]) == 8
+    assert j["config"]["mode"] == "loss" and j["config"]["N"] == 64 and j["config"]["batches_per_launch"] == 16384
+    assert j["scaling"] == "weak" and "dp8" in j["config"]["parallelism"] and "train_step" not in j
+    assert j["metric"].startswith("GE2E loss+backward throughput") and j["unit"] == "batches/s"
+
+
+def test_synth_is_generated_on_the_device_it_is_asked_for():
+    """bench.synth builds the embeddings where they will live (no host-side 10 GB block per rank): unit rows, seeded."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.synth(5, 3, 4, 64, 7, "cpu")
+    b = bench.synth(5, 3, 4, 64, 7, "cpu")
+    assert a.shape == (5, 3, 4, 64) and a.dtype == torch.float32 and torch.equal(a, b)
+    assert torch.allclose(a.norm(dim=-1), torch.ones(5, 3, 4), atol=1e-6)
+    assert not torch.equal(a, bench.synth(5, 3, 4, 64, 8, "cpu"))
+
+
 def test_gpus_1_stays_one_process():
     j = run("--gpus", "1")
     assert j["n_gpus"] == 1 and j["config"]["batches_per_launch"] == 16384 and j["config"]["mode"] == "loss"

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg5")
     ap.add_argument("--seconds", type=float, default=6.0)
+    ap.add_argument("--forward-only", action="store_true", help="dE = NULL: similarity + loss only")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     N, M, D, variant, B = cfg["N"], cfg["M"], cfg["D"], cfg["variant"], cfg["B"]
@@ -33,16 +34,17 @@ def main():
     e = bench.synth(B, N, M, D, 1234, dev)
     w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
     print("idle:", smi(), flush=True)
-    out = GF.loss_fwd_bwd(e, w, b, variant=variant)
+    ng = not args.forward_only
+    out = GF.loss_fwd_bwd(e, w, b, variant=variant, need_grad=ng)
     torch.cuda.synchronize()
     t_end = time.time() + args.seconds
     k = 0
     while time.time() < t_end:
         for _ in range(20):
-            out = GF.loss_fwd_bwd(e, w, b, variant=variant, out=out)
+            out = GF.loss_fwd_bwd(e, w, b, variant=variant, need_grad=ng, out=out)
         k += 1
         if k % 4 == 0:
-            print(f"{args.config}:", smi(), flush=True)
+            print(f"{args.config}{' forward-only' if args.forward_only else ''}:", smi(), flush=True)
         torch.cuda.synchronize()
 
 

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--impl", default="fused_f32")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batches", type=int, default=1024)
+    ap.add_argument("--forward-only", action="store_true", help="dE = NULL (similarity + loss only)")
     ap.add_argument("--no-build", action="store_true", help="use the libge2e_hip_prof.so that is there (built off the GPU box)")
     ap.add_argument("--lib", default="libge2e_hip_prof.so", help="file name of the stamped library inside the package directory")
     args = ap.parse_args()
@@ -79,7 +80,7 @@ def main():
 
     def run():
         code = lib.ge2e_loss_fwd_bwd(E.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), 1e-8, 1e-6, v, im,
-                                     loss.data_ptr(), None, dE.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                     loss.data_ptr(), None, None if args.forward_only else dE.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         assert code == 0, code
 
@@ -97,7 +98,7 @@ def main():
         cyc /= 8.0          # eight workgroups stamp every batch; report one workgroup's timeline
     tot = cyc.sum()
     names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])
-    print(f"{args.impl} {args.config} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
+    print(f"{args.impl} {args.config}{' forward-only' if args.forward_only else ''} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
           f"{tot:.0f} cycles per batch per workgroup")
     for i, n in enumerate(names):
         if i < len(cyc) and cyc[i] > 0:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: SQ instruction-mix / busy counters of the two cfg2 kernels (each --pmc set its own run).
 # usage: [CFG=cfg5] [IMPLS="auto team"] bash tools/run_sq_counters.sh   (writes gpurun_out/sq_<impl>_<set>/ and prints a digest,
-# per kernel name: the largest value over the launches)
+# per kernel name: the largest value over the launches)   EXTRA="--forward-only": the forward-only launch
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
 for impl in ${IMPLS:-auto team}; do
@@ -11,7 +11,7 @@ for impl in ${IMPLS:-auto team}; do
              "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU"; do
     out=$root/gpurun_out/sq_${impl}_$i
-    rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --config ${CFG:-cfg2} --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify --impl $impl > /dev/null 2> $out.log
+    rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --config ${CFG:-cfg2} --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify --impl $impl ${EXTRA:-} > /dev/null 2> $out.log
     i=$((i+1))
   done
 done
