@@ -39,6 +39,29 @@ __device__ __forceinline__ void split4(const float4& x, h4& hi, h4& lo) {
     lo = h4{(_Float16)(x.x - (float)hi[0]), (_Float16)(x.y - (float)hi[1]),
             (_Float16)(x.z - (float)hi[2]), (_Float16)(x.w - (float)hi[3])};
 }
+// (x * sc) -> hi + lo in ONE instruction per half: v_fma_mixlo / mixhi_f16 round the EXACT product x * sc once to fp16 (hi),
+// and the residual x * sc - hi is formed fused, from the very bits stored as hi, and rounded once (lo): 8 instructions per
+// float4 where scale + split4 takes 16, and the fp32 rounding of the scaled value is gone.  _u: `sc` is wave-uniform (an
+// SGPR operand -- no copy into a vector register).
+#define GE2E_SPLIT2_(H_, L_, X0_, X1_, SC_, C_)                                                                              \
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(H_) : "v"(X0_), C_(SC_));                                                   \
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(H_) : "v"(X1_), C_(SC_));                                                   \
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(L_) : "v"(X0_), C_(SC_), "v"(H_));       \
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(L_) : "v"(X1_), C_(SC_), "v"(H_))
+__device__ __forceinline__ void split4_scaled(const float4& x, float sc, h4& hi, h4& lo) {
+    uint2 h, l;
+    GE2E_SPLIT2_(h.x, l.x, x.x, x.y, sc, "v");
+    GE2E_SPLIT2_(h.y, l.y, x.z, x.w, sc, "v");
+    hi = __builtin_bit_cast(h4, h);
+    lo = __builtin_bit_cast(h4, l);
+}
+__device__ __forceinline__ void split4_scaled_u(const float4& x, float sc_uniform, h4& hi, h4& lo) {
+    uint2 h, l;
+    GE2E_SPLIT2_(h.x, l.x, x.x, x.y, sc_uniform, "s");
+    GE2E_SPLIT2_(h.y, l.y, x.z, x.w, sc_uniform, "s");
+    hi = __builtin_bit_cast(h4, h);
+    lo = __builtin_bit_cast(h4, l);
+}
 __device__ __forceinline__ float4 join4(const h4& hi, const h4& lo) {  // still scaled by kSplitScale
     return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
                        (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);

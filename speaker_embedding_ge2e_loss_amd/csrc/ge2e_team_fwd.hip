@@ -9,13 +9,13 @@
 // batches are in flight per workgroup and every long latency has most of an iteration to travel.
 //
 //   iteration n (cur = batch n of this team, prev = n - 1):
-//     A1(cur)   wave s = speaker slot s: sum of its M rows (registers RA, requested two iterations ago) -> unit centroid ->
+//     A1(cur)   wave s = speaker slot s: sum of its M rows (registers, requested two iterations ago) -> unit centroid ->
 //               published as MFMA fragments (fragment-major, ge2e_team.hip)
 //     X(prev)   X[slot][row] of prev on 16x16x32 split-fp16 MFMA: centroid fragments of prev in registers (requested at
 //               the end of the previous iteration), the member's e-hat images in LDS; wave (slot tile, K half) -> XB0 / XB1
 //     --        drain, BARRIER 1, one lane signals c1: cur's centroids are published (and prev's scalars, below)
 //     A2(cur)   wave s: |e| of its rows (one reduce-scatter), e-hat -> split-fp16 images (overwrites prev's: X(prev) is done)
-//     rows      RA <- RB (batch n + 1, requested an iteration ago); rows of batch n + 2 requested into RB
+//     rows      the rows of batch n + 2 requested into the registers A2 has just emptied (two register sets alternate)
 //     S(prev)   wave = speaker, 4 lanes per row, 16 similarities per lane from XB0 + XB1: leave-one-out cosine on the own
 //               column, softmax / contrast, per-row loss -> loss, (dw, db) partials
 //     W         one lane polls c1 for cur (signalled a phase and a half ago); BARRIER 2
@@ -135,7 +135,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     bool failed = false;
     int nsig = 0;                       // signals this member has given (every member gives the same number)
     const int wid_outer = wid, member_outer = id.member, tid_outer = tid, m_outer = M;
-    for (int seq = 0;; ++seq) {
+    // The body is written ONCE and expanded TWICE per loop trip, on alternating row-register sets: R0 holds the rows of the
+    // batch being started and is reloaded, in place, with the rows of batch n + 2 as soon as A2 has consumed it; the other
+    // set (batch n + 1, in flight) is not touched.  No register of an in-flight load is ever copied: with an explicit
+    // "RA <- RB" the allocator sank the copies to the latch behind an s_waitcnt for the loads just issued, and `break`s in
+    // the middle of the body made phis (and ~130 v_mov per trip) of the centroid fragments as well.  The trip behind the last
+    // batch (seq == nb) runs the same body with have_cur false; exits only between two expansions.
+    const int nb = id.team < p.B ? (p.B - id.team + id.nct - 1) / id.nct : 0;    // batches of this team
+    int seq = 0;
+    auto body = [&](float4 (&R0)[MR]) __attribute__((always_inline)) {
         // wave- and member-derived scalars are re-derived in every iteration from opaque copies (ge2e_team.hip, hazard 8)
         int wid_o = wid_outer, mem_o = member_outer, tid_o = tid_outer, m_o = m_outer;
         asm volatile("" : "+s"(wid_o), "+s"(mem_o), "+v"(tid_o), "+s"(m_o));
@@ -150,8 +158,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         const int rbase = wid * M;                         // first row of that speaker in the images
         const int tX = wid & 3, khX = wid >> 2;            // X: slot tile and K half of this wave
         const int bi = id.team + seq * id.nct;             // batch started in this iteration
-        const bool have_cur = bi < p.B, have_prev = seq > 0;
-        if (!have_cur && !have_prev) break;
+        const bool have_cur = seq < nb, have_prev = seq > 0;
         const int buf = seq & 1, pbuf = buf ^ 1;
         sn_prev = sn_cur; ss_prev = ss_cur;
 
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             float4 s = zero4();
 #pragma unroll
             for (int i = 0; i < MR; ++i)
-                if (i < M) { s.x += ra[i].x; s.y += ra[i].y; s.z += ra[i].z; s.w += ra[i].w; }
+                if (i < M) { s.x += R0[i].x; s.y += R0[i].y; s.z += R0[i].z; s.w += R0[i].w; }
             const float4 c = scale4(s, inv_m);
             float sqs[2] = {dot4(c, c), dot4(s, s)};
             wave_sum_to_sgpr<2>(sqs);
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             sn_cur = has_spk ? fM * nc : 0.f;
             ss_cur = has_spk ? sqs[1] : 0.f;
             h4 hi, lo;
-            split4(scale4(c, rn * kSplitScale), hi, lo);
+            split4_scaled(c, rn * kSplitScale, hi, lo);
             // one 1-KB block per (slot tile, hi / lo, 32-column K-step) holding the 64 lanes' 16-byte MFMA fragments in lane
             // order (lane = 16 q + slot-in-tile): a consumer's load instruction reads 1 KB contiguously
             const unsigned blk = (unsigned)(kslot >> 4) * (4u * NCH) + (unsigned)(lv_ >> 3);
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             GE2E_TF_CONSTS();
             float eev[MR];
 #pragma unroll
-            for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(ra[i], ra[i]) : 0.f;
+            for (int i = 0; i < MR; ++i) eev[i] = i < M ? dot4(R0[i], R0[i]) : 0.f;
             const float ee_l = wave_sums_scatter<MR>(eev, lv_);      // row i's |e|^2 in lane scatter_lane(i)
             float rne_l, ke_l, ne_l;
             unit_stats_bf(ee_l, eps_cos, eps_cos2, rne_l, ke_l, ne_l);
@@ -253,15 +260,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float sc = lane_get(rs_l, scatter_lane(i));
-                    if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(ra[i], sc));
+                    if (dact) {
+                        h4 hi, lo;
+                        split4_scaled_u(R0[i], sc, hi, lo);
+                        const int eo = et_off<D>(rbase + i, d4);
+                        *reinterpret_cast<h4*>(ETh + eo) = hi;
+                        *reinterpret_cast<h4*>(ETl + eo) = lo;
+                    }
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
         }
-        // ---- RA <- RB (requested an iteration ago), batch n + 2 requested into RB: it has until the next-but-one A1
-#pragma unroll
-        for (int i = 0; i < MR; ++i) ra[i] = rb2[i];
-        GE2E_TF_LOAD_ROWS(rb2, bi + 2 * id.nct);
+        // ---- the rows of batch n + 2 into the registers A2 has just finished with: they have until the next-but-one A1
+        GE2E_TF_LOAD_ROWS(R0, bi + 2 * id.nct);
         GE2E_PROF(4);
 
         // ===== S(prev): leave-one-out statistics, softmax / contrast, per-row loss ==================================
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             int* const wsh = SH + 4 + (seq & 3);
             if (tid == 0) *wsh = spin_until(&fl->c1, (unsigned)(TEAM * nsig), ctl) ? 1 : 0;
             __syncthreads();                 // also: the images, row scalars and RED are written; XB has been read
-            if (*wsh == 0) { failed = true; break; }
+            failed = *wsh == 0;              // (uniform; the loop ends below, behind requests that are harmless then)
         }
         GE2E_PROF(6);
 
@@ -425,7 +436,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             }
         }
         GE2E_PROF(7);
-        if (!have_cur) break;            // that was the iteration behind the last batch
+        ++seq;
+    };
+    if (nb > 0) for (;;) {
+        body(ra);
+        if (seq > nb || failed) break;
+        body(rb2);
+        if (seq > nb || failed) break;
     }
     // ---- tail: the scalars of the last two batches.  The loop ended with iteration L (= this team's batch count): batch
     // L - 2 went to the exchange in iteration L - 1 and was covered by iteration L's signal; batch L - 1 went out just now.
@@ -433,7 +450,6 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         int mem_o = member_outer, tid_o = tid_outer;
         asm volatile("" : "+s"(mem_o), "+v"(tid_o));
         const int tid = tid_o, lane = tid & 63;
-        const int nb = id.team < p.B ? (p.B - id.team + id.nct - 1) / id.nct : 0;    // batches of this team = L
         if (nb > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

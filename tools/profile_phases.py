@@ -40,6 +40,10 @@ PHASES = {
     "tiled": ["sim: until the first stage landed", "sim: K loop", "sim: epilogue issued", "sim: stores drained", "sim loop: slice-1 reads + 24 MFMAs issued", "sim loop: own pieces landed", "sim loop: barrier", "sim loop: pieces + slice-0 reads + 24 MFMAs issued",
               "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: slice-1 reads + 24 MFMAs issued", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: pieces + slice-0 reads + 24 MFMAs issued",
               "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: slice-1 reads + 24 MFMAs issued", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: pieces + slice-0 reads + 24 MFMAs issued"],
+    # the pipelined forward-only team kernel (csrc/ge2e_team_fwd.hip)
+    "team_fwd": ["A1(cur) speaker sum -> centroid published", "X(prev) contraction -> XB", "drain (vmcnt 0)", "barrier 1 + signal",
+                 "A2(cur) rows -> images; RA <- RB; rows of n + 2 requested", "S(prev) softmax, loss", "poll c1(cur) + barrier 2",
+                 "requests: centroid fragments; member scalars"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -97,7 +101,7 @@ def main():
     if args.impl in ("team", "team"):
         cyc /= 8.0          # eight workgroups stamp every batch; report one workgroup's timeline
     tot = cyc.sum()
-    names = PHASES.get(args.impl, [f"phase {i}" for i in range(10)])
+    names = PHASES.get(args.impl + ("_fwd" if args.forward_only else ""), PHASES.get(args.impl, [f"phase {i}" for i in range(10)]))
     print(f"{args.impl} {args.config}{' forward-only' if args.forward_only else ''} B={B}: launch {t0.elapsed_time(t1):.3f} ms (stamped build); "
           f"{tot:.0f} cycles per batch per workgroup")
     for i, n in enumerate(names):
