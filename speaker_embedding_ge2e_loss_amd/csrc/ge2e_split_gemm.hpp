@@ -62,6 +62,24 @@ __device__ __forceinline__ void split4_scaled_u(const float4& x, float sc_unifor
     hi = __builtin_bit_cast(h4, h);
     lo = __builtin_bit_cast(h4, l);
 }
+// the two halves of split4_scaled_u as separate steps (callers interleave several vectors' chains)
+__device__ __forceinline__ void split4_scaled_hi_u(const float4& x, float sc_uniform, h4& hi) {
+    uint2 h;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h.x) : "v"(x.x), "s"(sc_uniform));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h.y) : "v"(x.z), "s"(sc_uniform));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h.x) : "v"(x.y), "s"(sc_uniform));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h.y) : "v"(x.w), "s"(sc_uniform));
+    hi = __builtin_bit_cast(h4, h);
+}
+__device__ __forceinline__ void split4_scaled_lo_u(const float4& x, float sc_uniform, const h4& hi, h4& lo) {
+    const uint2 h = __builtin_bit_cast(uint2, hi);
+    uint2 l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l.x) : "v"(x.x), "s"(sc_uniform), "v"(h.x));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l.y) : "v"(x.z), "s"(sc_uniform), "v"(h.y));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l.x) : "v"(x.y), "s"(sc_uniform), "v"(h.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l.y) : "v"(x.w), "s"(sc_uniform), "v"(h.y));
+    lo = __builtin_bit_cast(h4, l);
+}
 __device__ __forceinline__ float4 join4(const h4& hi, const h4& lo) {  // still scaled by kSplitScale
     return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
                        (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);

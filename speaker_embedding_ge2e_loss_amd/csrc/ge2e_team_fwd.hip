@@ -10,7 +10,7 @@
 //
 //   iteration n (cur = batch n of this team, prev = n - 1):
 //     A1(cur)   wave s = speaker slot s: sum of its M rows (registers, requested two iterations ago) -> unit centroid ->
-//               published as MFMA fragments (fragment-major, ge2e_team.hip)
+//               published as MFMA fragments (fragment-major, ge2e_team.hip); prev's fragments requested underneath
 //     X(prev)   X[slot][row] of prev on 16x16x32 split-fp16 MFMA: centroid fragments of prev in registers (requested at
 //               the end of the previous iteration), the member's e-hat images in LDS; wave (slot tile, K half) -> XB0 / XB1
 //     --        drain, BARRIER 1, one lane signals c1: cur's centroids are published (and prev's scalars, below)
@@ -19,8 +19,9 @@
 //     S(prev)   wave = speaker, 4 lanes per row, 16 similarities per lane from XB0 + XB1: leave-one-out cosine on the own
 //               column, softmax / contrast, per-row loss -> loss, (dw, db) partials
 //     W         one lane polls c1 for cur (signalled a phase and a half ago); BARRIER 2
-//     requests  centroid fragments of cur from L2 -> registers; member scalars of prev -> exchange; member 0 sums the eight
-//               members' scalars of batch n - 2 (made visible by this iteration's hand-off) -> loss / dw / db
+//     scalars   member scalars of prev -> exchange; member 0 sums the eight members' scalars of batch n - 2 (made visible by
+//               this iteration's hand-off) -> loss / dw / db.  (cur's centroid fragments are requested from L2 at the top of
+//               the next iteration, one load at a time between the instruction groups of its A1.)
 //   Two workgroup barriers per batch.  HBM latency has the whole iteration (rows), the hand-off has A2 + S, the L2 round
 //   trip of the fragments has A1.  After the last batch two extra signals carry the last two batches' scalars to member 0.
 //
@@ -99,11 +100,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     __syncthreads();
 
     float4 ra[MR], rb2[MR];     // this wave's rows: RA = the batch about to start, RB = the one after it (in flight)
-    h8 xa[NCH][2];              // centroid fragments of the batch X works on: slots 16 tX + l15, K-steps khX NCH + s, 8 q ..
     float sn_cur = 0.f, ss_cur = 0.f, sn_prev = 0.f, ss_prev = 0.f;   // |s_j| (clamped), |s_j|^2 of this wave's speaker
-#pragma unroll
-    for (int s = 0; s < NCH; ++s) { xa[s][0] = h8{}; xa[s][1] = h8{}; }
-
     // every load unconditional: a disabled one gets an out-of-bounds offset (the buffer resource returns zeros)
 #define GE2E_TF_LOAD_ROWS(REG, BI)                                                                       \
     do {                                                                                                 \
@@ -114,6 +111,29 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
             REG[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+    } while (0)
+// falling issue priority from barrier to barrier (the remedy of hazard 23 in the tiled contractions: the wave that is behind
+// wins ties) measured -1 % here, as in the training kernel: off unless -DGE2E_TF_WITH_PRIO
+#ifdef GE2E_TF_WITH_PRIO
+#define GE2E_TF_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define GE2E_TF_PRIO(n)
+#endif
+// the same loads one row at a time (S issues them between its instruction groups): LOADR_SETUP once, then LOADR(REG, i)
+#define GE2E_TF_LOADR_SETUP(BI)                                                                          \
+    int lq_ = lane;                                                                                      \
+    asm volatile("" : "+v"(lq_));                                                                        \
+    const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                      \
+    const bool on_ = has_spk && (BI) < p.B;                                                              \
+    const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB)
+#define GE2E_TF_LOADR(REG, I_)                                                                           \
+    do {                                                                                                 \
+        if ((I_) < MR) {                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            REG[(I_) < MR ? (I_) : 0] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && (I_) < M) ? vrow_ : OOB,      \
+                                                              (unsigned)(j * M + min((I_), M - 1)) * ROWB); \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
     } while (0)
 #define GE2E_TF_LANE()                                                  \
     int lv_ = lane;                                                     \
@@ -162,14 +182,34 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         const int buf = seq & 1, pbuf = buf ^ 1;
         sn_prev = sn_cur; ss_prev = ss_cur;
 
+        // ===== requests: prev's centroid fragments (all members', complete since the poll at the end of the last iteration)
+        // -> registers, for X(prev) below.  2 NCH loads of 1 KB per wave = 64 KB per workgroup through the CU's 64 B/clk
+        // address path: issued in one go all eight waves stand at load issue for ~1 k cycles; they go out BETWEEN the
+        // instruction groups of A1 instead, whose vector work covers them.
+        h8 xa[NCH][2];          // slots 16 tX + l15, K-steps khX NCH + s, 8 q ..
+        int lx_ = lane;
+        asm volatile("" : "+v"(lx_));
+        const unsigned oa = have_prev ? XO.chr[pbuf] + ((unsigned)tX * (4u * NCH) + (unsigned)khX * NCH) * 1024u + (unsigned)lx_ * 16u : OOB;
+#define GE2E_TF_XA_LOAD(K_)                                                                                        \
+    do {                                                                                                           \
+        if ((K_) < 2 * NCH) {                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            xa[((K_) < 2 * NCH ? (K_) : 0) >> 1][(K_) & 1] =                                                       \
+                bload_h8<AUX_L2>(rsX, oa + 1024u * (unsigned)((K_) >> 1) + (((K_) & 1) ? 2048u * NCH : 0u), 0);    \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+    } while (0)
+        if (!have_cur) static_for<0, 2 * NCH>([&](auto kc) { GE2E_TF_XA_LOAD(decltype(kc)::value); });
         // ===== A1(cur): speaker sum -> unit centroid -> published (fragment-major) ==================================
         if (have_cur) {
             GE2E_TF_LANE();
             GE2E_TF_CONSTS();
             float4 s = zero4();
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
+            static_for<0, MR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 if (i < M) { s.x += R0[i].x; s.y += R0[i].y; s.z += R0[i].z; s.w += R0[i].w; }
+                GE2E_TF_XA_LOAD(i);                        // (K_ >= 2 NCH: nothing)
+            });
             const float4 c = scale4(s, inv_m);
             float sqs[2] = {dot4(c, c), dot4(s, s)};
             wave_sum_to_sgpr<2>(sqs);
@@ -188,19 +228,26 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, 0);
         }
         GE2E_PROF(0);
+        GE2E_TF_PRIO(1);
 
         // ===== X(prev): X[slot][r] over this wave's K half -> LDS (fragments of the next K-step under the MFMAs) ======
+        auto phase_x = [&]() __attribute__((always_inline)) {
         if (have_prev) {
             GE2E_TF_LANE();
             float* const XBk = khX ? XB1 : XB0;
             const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   // et_off's f of rows 16 rb + l15
             h8 fb[2][2];
             f32x4 acc[2] = {acc_zero4(), acc_zero4()};
+            // the swizzle depends on the row only through l15 (period 16): one lane offset per K-step, the row block and the
+            // lo image are immediates (written per load, hipcc re-derived the XOR for each of the 20 fragments: 50 VALU)
+            int xs[NCH];
+#pragma unroll
+            for (int s2 = 0; s2 < NCH; ++s2) xs[s2] = l15 * P + (((4 * (khX * NCH + s2) + q) ^ fx) << 3);
 #define TF_X_LOAD(T_)                                                                                     \
     do {                                                                                                  \
-        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
-        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
-        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
+        const _Float16* const pp_ = ETh + xs[(T_) % NCH] + 16 * ((T_) / NCH) * P;                         \
+        fb[(T_) & 1][0] = frag_row(pp_);                                                                  \
+        fb[(T_) & 1][1] = frag_row(pp_ + RT * P);                                                         \
     } while (0)
 #define TF_X_STORE(RB_)                                                                       \
     *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
@@ -229,6 +276,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
 #undef TF_X_LOAD
 #undef TF_X_STORE
         }
+        };
+        phase_x();
         GE2E_PROF(1);
 
         // ---- drain + BARRIER 1: cur's centroid is in L2 (and the member scalars of prev - 1); X(prev) is in LDS and the
@@ -239,8 +288,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         if (tid == 0) add_agent(&fl->c1, 1u);
         ++nsig;
         GE2E_PROF(3);
+        GE2E_TF_PRIO(3);
 
-        // ===== A2(cur): own rows -> |e|, e-hat -> images ============================================================
+        // ===== A2(cur), compute half: own rows -> |e|, e-hat as split-fp16 halves in registers; the row scalars go to their parity buffer
+        h4 hiv[MR], lov[MR];
+        auto phase_a2c = [&]() __attribute__((always_inline)) {
         if (have_cur && has_spk) {
             GE2E_TF_LANE();
             GE2E_TF_CONSTS();
@@ -256,24 +308,42 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
                     *reinterpret_cast<float4*>(RS + (buf * RT + rbase + irow) * 4) = make_float4(rne_l, ke_l, ee_l, ne_l);
             }
             const float rs_l = rne_l * kSplitScale;
+            // all rows' hi halves, then all lo halves: a row's split is a chain of dependent mixed-precision FMAs; ten rows
+            // side by side fill each other's latencies
+            float scv[MR];
 #pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                if (i < M) {
-                    const float sc = lane_get(rs_l, scatter_lane(i));
-                    if (dact) {
-                        h4 hi, lo;
-                        split4_scaled_u(R0[i], sc, hi, lo);
-                        const int eo = et_off<D>(rbase + i, d4);
-                        *reinterpret_cast<h4*>(ETh + eo) = hi;
-                        *reinterpret_cast<h4*>(ETl + eo) = lo;
-                    }
-                }
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
-            }
+            for (int i = 0; i < MR; ++i) scv[i] = lane_get(rs_l, scatter_lane(i));
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M) split4_scaled_hi_u(R0[i], scv[i], hiv[i]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M) split4_scaled_lo_u(R0[i], scv[i], hiv[i], lov[i]);
         }
-        // ---- the rows of batch n + 2 into the registers A2 has just finished with: they have until the next-but-one A1
-        GE2E_TF_LOAD_ROWS(R0, bi + 2 * id.nct);
+        };
+        // (Tried: X(prev) -- matrix pipe -- and this compute half -- vector pipe -- in OPPOSITE order on the two waves of a SIMD,
+        // in front of barrier 1: -6 %.  The same pairing of S(prev) with A2(cur): -5 %.  An MFMA in flight costs the partner
+        // wave's vector stream ~6 cycles per instruction, tools/ubench: the two pipes of a SIMD do not run side by side.)
+        phase_a2c();
+        // ===== A2(cur), write half: e-hat halves -> images (X(prev) is done everywhere: barrier 1) ====================
+        if (have_cur && has_spk) {
+            GE2E_TF_LANE();
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                if (i < M && dact) {
+                    const int eo = et_off<D>(rbase + i, d4);
+                    *reinterpret_cast<h4*>(ETh + eo) = hiv[i];
+                    *reinterpret_cast<h4*>(ETl + eo) = lov[i];
+                }
+        }
+        // ---- the rows of batch n + 2 into the registers A2 has just finished with: they have until the next-but-one A1.
+        // All eight waves asking for their 10 KB at the same point stand at load issue for ~1.3 k cycles (80 KB through the
+        // CU's 64 B/clk address path); where there is an S(prev) to run, the requests go out one at a time BETWEEN its
+        // instruction groups instead and the address path works underneath the vector work.
+        const bool spread_loads = have_prev && has_spk;
+        if (!spread_loads) GE2E_TF_LOAD_ROWS(R0, bi + 2 * id.nct);
         GE2E_PROF(4);
+        GE2E_TF_PRIO(1);
 
         // ===== S(prev): leave-one-out statistics, softmax / contrast, per-row loss ==================================
         // Wave s = speaker slot s: FOUR lanes per row, 16 similarities per lane.  Lane (rr = lane >> 2, qq = lane & 3) holds
@@ -293,14 +363,23 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             const bool own_lane = qq == 0;
             const bool all_valid = N == NC;
             const bool want_wb = p.dw != nullptr || p.db != nullptr;
+            GE2E_TF_LOADR_SETUP(bi + 2 * id.nct);
             float x[16];
+            float4 xa4[4], xb4[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int s4 = (sb + 4 * jj) & (NC - 1);
-                const float4 a = *reinterpret_cast<const float4*>(XB0 + r * XP + s4);
-                const float4 b = *reinterpret_cast<const float4*>(XB1 + r * XP + s4);
-                x[4 * jj + 0] = a.x + b.x; x[4 * jj + 1] = a.y + b.y; x[4 * jj + 2] = a.z + b.z; x[4 * jj + 3] = a.w + b.w;
+                xa4[jj] = *reinterpret_cast<const float4*>(XB0 + r * XP + s4);
+                xb4[jj] = *reinterpret_cast<const float4*>(XB1 + r * XP + s4);
             }
+            GE2E_TF_LOADR(R0, 0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 a = xa4[jj], b = xb4[jj];
+                x[4 * jj + 0] = a.x + b.x; x[4 * jj + 1] = a.y + b.y; x[4 * jj + 2] = a.z + b.z; x[4 * jj + 3] = a.w + b.w;
+                if (jj == 1) GE2E_TF_LOADR(R0, 1);
+            }
+            GE2E_TF_LOADR(R0, 2);
             const float xo = (XB0[r * XP + ko] + XB1[r * XP + ko]) * kSplitInv2;   // c-hat_j . e-hat_r
             const float4 rs0 = *reinterpret_cast<const float4*>(RS + (pbuf * RT + r) * 4);    // rne ke ee |e|
             const float rne = rs0.x, ee = rs0.z, ne = rs0.w;
@@ -310,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             float rnu, ku, nu;
             unit_stats_bf(uu, eps_cos, eps_cos2, rnu, ku, nu);
             const float cosd = eu * rne * rnu;               // cos(e, leave-one-out centroid)
+            GE2E_TF_LOADR(R0, 3);
             const float sjj2 = fmaf(w2, cosd, b2);
             const float w2s = w2 * kSplitInv2;               // S2 = w2s x + b2 on the raw accumulator sums
             auto vld = [&](int jx) {
@@ -320,6 +400,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) ownj[jx] = own_lane && jo == jx;
             float per, coefsum = 0.f, db_row = 0.f;
+            GE2E_TF_PRIO(0);
+            GE2E_TF_LOADR(R0, 4);
             if (!CONTRAST) {
                 float xm0 = ownj[0] ? x[1] : x[0], xm1 = ownj[1] ? x[0] : x[1], xm2 = ownj[2] ? x[3] : x[2], xm3 = ownj[3] ? x[2] : x[3];
                 float xm;
@@ -332,24 +414,33 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
 #pragma unroll
                     for (int jx = 4; jx < 16; jx += 2) xm = fminf(fminf(x[jx], x[jx + 1]), xm);
                 }
+                GE2E_TF_LOADR(R0, 5);
                 float mx = quad_max(fmaf(w2s, xm, b2));
                 mx = fmaxf(fmaxf(mx, sjj2), leps2);
                 const float t = b2 - mx;
                 float gv[16];
 #pragma unroll
-                for (int jx = 0; jx < 16; ++jx) gv[jx] = __builtin_amdgcn_exp2f(fmaf(w2s, x[jx], t));
+                for (int jx = 0; jx < 16; ++jx) {
+                    gv[jx] = __builtin_amdgcn_exp2f(fmaf(w2s, x[jx], t));
+                    if ((jx & 3) == 3) GE2E_TF_LOADR(R0, 6 + (jx >> 2));
+                }
+                static_for<10, MR>([&](auto ic) { GE2E_TF_LOADR(R0, decltype(ic)::value); });
                 if (!all_valid) {
 #pragma unroll
                     for (int jx = 0; jx < 16; ++jx) gv[jx] = vld(jx) ? gv[jx] : 0.f;
                 }
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) gv[jx] = ownj[jx] ? 0.f : gv[jx];
-                float zl = 0.f, al = 0.f;
+                // four partial sums side by side (one chain of 16 dependent adds is 16 x 8.9 cycles of latency)
+                float z4[4] = {gv[0], gv[1], gv[2], gv[3]}, a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jx = 0; jx < 16; ++jx) zl += gv[jx];
+                for (int jx = 4; jx < 16; ++jx) z4[jx & 3] += gv[jx];
+                const float zl = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+                float al = 0.f;
                 if (want_wb) {
 #pragma unroll
-                    for (int jx = 0; jx < 16; ++jx) al = fmaf(gv[jx], x[jx], al);
+                    for (int jx = 0; jx < 16; ++jx) a4[jx & 3] = fmaf(gv[jx], x[jx], a4[jx & 3]);
+                    al = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 }
                 const float zp = quad_sum(zl);                // sum over the other speakers, shifted
                 const float zoff = zp + __builtin_amdgcn_exp2f(leps2 - mx);
@@ -363,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
                     db_row = fmaf(zp, rz, ad0);
                 }
             } else {
+                static_for<5, MR>([&](auto ic) { GE2E_TF_LOADR(R0, decltype(ic)::value); });
                 float best = -INFINITY, bx = 0.f; int besti = 0x7fffffff;
 #pragma unroll
                 for (int jx = 0; jx < 16; ++jx) {
@@ -392,9 +484,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         __builtin_amdgcn_sched_barrier(0);
         // ---- member scalars: fixed-order reduction over the 8 waves ------------------------------------------------
         if (have_prev) {
-            float v3[3] = {loss_acc, dw_acc, db_acc};
-            wave_sum_to_sgpr<3>(v3);
-            if (lane == 0) { RED[wid] = v3[0]; RED[8 + wid] = v3[1]; RED[16 + wid] = v3[2]; }
+            if (p.dw != nullptr || p.db != nullptr) {
+                float v3[3] = {loss_acc, dw_acc, db_acc};
+                wave_sum_to_sgpr<3>(v3);
+                if (lane == 0) { RED[wid] = v3[0]; RED[8 + wid] = v3[1]; RED[16 + wid] = v3[2]; }
+            } else {
+                float v1[1] = {loss_acc};
+                wave_sum_to_sgpr<1>(v1);
+                if (lane == 0) { RED[wid] = v1[0]; RED[8 + wid] = 0.f; RED[16 + wid] = 0.f; }
+            }
         }
         GE2E_PROF(5);
 
@@ -406,17 +504,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             failed = *wsh == 0;              // (uniform; the loop ends below, behind requests that are harmless then)
         }
         GE2E_PROF(6);
+        GE2E_TF_PRIO(3);
 
-        // ===== requests: cur's centroid fragments -> registers (used by X in the next iteration) =====================
-        {
-            GE2E_TF_LANE();
-            const unsigned oa = have_cur ? XO.chr[buf] + ((unsigned)tX * (4u * NCH) + (unsigned)khX * NCH) * 1024u + (unsigned)lv_ * 16u : OOB;
-#pragma unroll
-            for (int s = 0; s < NCH; ++s) {
-                xa[s][0] = bload_h8<AUX_L2>(rsX, oa + 1024u * s, 0);
-                xa[s][1] = bload_h8<AUX_L2>(rsX, oa + 1024u * s + 2048u * NCH, 0);
-            }
-        }
+        // (cur's centroid fragments are requested at the top of the next iteration, between the instruction groups of its A1)
         // ---- member scalars of prev -> exchange (visible to member 0 after the NEXT signal); member 0: batch n - 2 out
         if (have_prev && tid == 0) {
             float l = 0.f, a = 0.f, c = 0.f;
@@ -436,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             }
         }
         GE2E_PROF(7);
+        GE2E_TF_PRIO(2);
         ++seq;
     };
     if (nb > 0) for (;;) {
