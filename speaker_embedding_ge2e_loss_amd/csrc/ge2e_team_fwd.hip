@@ -155,6 +155,19 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     bool failed = false;
     int nsig = 0;                       // signals this member has given (every member gives the same number)
     const int wid_outer = wid, member_outer = id.member, tid_outer = tid, m_outer = M;
+    float4 sc_pend = zero4();           // member 0, wave 0: the eight members' scalars of batch sc_batch, requested, not yet summed
+    int sc_batch = -1;
+    auto sc_flush = [&]() __attribute__((always_inline)) {
+        if (sc_batch >= 0) {            // (uniform: set by member 0's wave 0 only)
+            const float l = oct_sum(sc_pend.x), a = oct_sum(sc_pend.y), c = oct_sum(sc_pend.z);
+            if ((threadIdx.x & 63) == 0) {
+                if (p.loss) p.loss[sc_batch] = l;
+                if (p.dw) p.dw[sc_batch] = a;
+                if (p.db) p.db[sc_batch] = c;
+            }
+            sc_batch = -1;
+        }
+    };
     // The body is written ONCE and expanded TWICE per loop trip, on alternating row-register sets: R0 holds the rows of the
     // batch being started and is reloaded, in place, with the rows of batch n + 2 as soon as A2 has consumed it; the other
     // set (batch n + 1, in flight) is not touched.  No register of an in-flight load is ever copied: with an explicit
@@ -278,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         }
         };
         phase_x();
+        sc_flush();
         GE2E_PROF(1);
 
         // ---- drain + BARRIER 1: cur's centroid is in L2 (and the member scalars of prev - 1); X(prev) is in LDS and the
@@ -514,16 +528,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
             for (int i = 0; i < 8; ++i) { l += RED[i]; a += RED[8 + i]; c += RED[16 + i]; }
             bstore4(rsX, SC4 + (unsigned)((seq - 1) & 3) * 128u + (unsigned)id.member * 16u, make_float4(l, a, c, 0.f));
         }
+        // (requested here, summed and written a phase later -- sc_flush, behind the next X: member 0 must not stand in front of
+        // an L2 round trip that the other seven members then wait for at the next hand-off)
         if (seq >= 2 && id.member == 0 && wid == 0) {
             GE2E_TF_LANE();
-            const float4 scv = bload4<AUX_L2>(rsX, lv_ < TEAM ? SC4 + (unsigned)((seq - 2) & 3) * 128u + (unsigned)lv_ * 16u : OOB, 0);
-            const float l = oct_sum(scv.x), a = oct_sum(scv.y), c = oct_sum(scv.z);
-            if (lane == 0) {
-                const int bo = bi - 2 * id.nct;
-                if (p.loss) p.loss[bo] = l;
-                if (p.dw) p.dw[bo] = a;
-                if (p.db) p.db[bo] = c;
-            }
+            sc_pend = bload4<AUX_L2>(rsX, lv_ < TEAM ? SC4 + (unsigned)((seq - 2) & 3) * 128u + (unsigned)lv_ * 16u : OOB, 0);
+            sc_batch = bi - 2 * id.nct;
         }
         GE2E_PROF(7);
         GE2E_TF_PRIO(2);
@@ -537,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     }
     // ---- tail: the scalars of the last two batches.  The loop ended with iteration L (= this team's batch count): batch
     // L - 2 went to the exchange in iteration L - 1 and was covered by iteration L's signal; batch L - 1 went out just now.
+    if (!failed) sc_flush();
     if (!failed) {
         int mem_o = member_outer, tid_o = tid_outer;
         asm volatile("" : "+s"(mem_o), "+v"(tid_o));
