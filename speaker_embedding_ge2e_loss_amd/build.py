@@ -73,7 +73,7 @@ def _compile_one(args):
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every csrc/*.hip to an object (in parallel, only the stale ones) and link one shared object."""
     if not force and not is_stale():
-        build_torch_ext(force=False, verbose=verbose)
+        _build_torch_ext_optional(False, verbose)
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -92,15 +92,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("[ge2e build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    build_torch_ext(force=True, verbose=verbose)
+    _build_torch_ext_optional(True, verbose)
     return LIB_PATH
 
 
+TORCH_EXT_STAMP = TORCH_EXT_PATH + ".stamp"      # the torch version the extension was compiled against
+
+
 def torch_ext_is_stale() -> bool:
+    """Older than its source / the header / the core library it links, or built against another torch."""
     if not os.path.exists(TORCH_EXT_PATH):
         return True
     t = os.path.getmtime(TORCH_EXT_PATH)
-    return any(os.path.getmtime(d) > t for d in [TORCH_EXT_SRC] + glob.glob(os.path.join(INCLUDE, "*.h")))
+    deps = [TORCH_EXT_SRC] + glob.glob(os.path.join(INCLUDE, "*.h")) + ([LIB_PATH] if os.path.exists(LIB_PATH) else [])
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:
+        import torch
+        with open(TORCH_EXT_STAMP) as f:
+            return f.read().strip() != torch.__version__
+    except OSError:
+        return True
 
 
 def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
@@ -123,7 +135,21 @@ def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
         print("[ge2e build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(TORCH_EXT_PATH + ".tmp", TORCH_EXT_PATH)
+    with open(TORCH_EXT_STAMP, "w") as f:
+        f.write(torch.__version__)
     return TORCH_EXT_PATH
+
+
+def _build_torch_ext_optional(force: bool, verbose: bool) -> None:
+    """The C++ autograd node is an accelerator of the host path, not a requirement: without g++ (or with a torch whose
+    headers do not compile it) the Python node makes the same launches.  Say so and go on."""
+    try:
+        build_torch_ext(force=force, verbose=verbose)
+    except (RuntimeError, subprocess.CalledProcessError, OSError) as ex:
+        print(f"[ge2e build] libge2e_torch.so not built ({str(ex)[:160]}): the Python autograd node will be used", flush=True)
+        for stale in (TORCH_EXT_PATH, TORCH_EXT_STAMP):
+            if os.path.exists(stale):
+                os.remove(stale)
 
 
 def build_variant(out_path: str, defs: list[str], verbose: bool = False) -> str:

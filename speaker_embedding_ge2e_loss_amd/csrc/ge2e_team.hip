@@ -979,7 +979,15 @@ hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     f.grid_cap = team_fallback_grid(p.B);
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
                                     align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange(p.D).stride, 256));
-    return launch_fused_split(f, stream);
+    err = launch_fused_split(f, stream);
+    if (err != hipSuccess) {
+        // The team kernel is queued and NOTHING behind it will clean the control block (tickets, arrival count, hand-off
+        // counters, magic still set): the next call would form teams from stale tickets.  Rewrite a clean block behind it
+        // (stream order) and report the launch error.
+        launch_team_head_init(p_in.ws, L.head_bytes, false, stream);
+        return err;
+    }
+    return hipSuccess;
 }
 
 }  // namespace ge2e

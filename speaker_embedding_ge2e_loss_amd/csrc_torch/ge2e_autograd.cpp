@@ -28,9 +28,11 @@ void check(int code, const char* what) {
 // Per-(device, stream) workspace, like functional._workspace_for: reused only by launches on the same stream (which the
 // stream serialises), bypassed while the stream is being captured (the graph's private pool owns that allocation), at most
 // eight entries.  ge2e_workspace_init once per allocation: the first call on it already runs the team kernel.
+struct WsEntry { at::Tensor ws; uint64_t used; };
 struct WsCache {
     std::mutex mu;
-    std::map<std::pair<int, void*>, at::Tensor> m;
+    std::map<std::pair<int, void*>, WsEntry> m;
+    uint64_t tick = 0;
 };
 WsCache& ws_cache() { static WsCache c; return c; }
 
@@ -45,11 +47,29 @@ at::Tensor workspace_for(size_t need, const at::Device& dev, hipStream_t stream)
     std::lock_guard<std::mutex> lock(c.mu);
     const auto key = std::make_pair((int)dev.index(), (void*)stream);
     auto it = c.m.find(key);
-    if (it != c.m.end() && (size_t)it->second.numel() >= need) return it->second;
-    if (it == c.m.end() && c.m.size() >= 8) c.m.erase(c.m.begin());
+    if (it != c.m.end() && (size_t)it->second.ws.numel() >= need) {
+        it->second.used = ++c.tick;
+        return it->second.ws;
+    }
+    if (it == c.m.end() && c.m.size() >= 8) {          // least recently used out (not the smallest key: that is the default stream's)
+        auto lru = c.m.begin();
+        for (auto j = c.m.begin(); j != c.m.end(); ++j)
+            if (j->second.used < lru->second.used) lru = j;
+        c.m.erase(lru);
+    }
     at::Tensor ws = new_workspace(need, dev, stream);
-    c.m[key] = ws;
+    c.m[key] = WsEntry{ws, ++c.tick};
     return ws;
+}
+// the workspace this node would use for `like`'s device on the current stream (an empty tensor when there is none yet):
+// diagnostics -- functional.workspace_fallback_count reads TeamCtl.fallbacks from it
+at::Tensor cached_workspace(const at::Tensor& like) {
+    TORCH_CHECK(like.is_cuda(), "cached_workspace: a ROCm device tensor names the device");
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(like.device().index()).stream();
+    WsCache& c = ws_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.m.find(std::make_pair((int)like.device().index(), (void*)stream));
+    return it == c.m.end() ? at::empty({0}, at::TensorOptions().dtype(at::kByte).device(like.device())) : it->second.ws;
 }
 
 // one ge2e_loss_fwd_bwd launch on the current stream; need: also dE, dw, db (sc = loss | dw | db, [3][B], else [1][B])
@@ -89,8 +109,8 @@ struct GE2ELossNode : public torch::autograd::Function<GE2ELossNode> {
                               double eps, double eps_cos, int64_t variant, int64_t impl) {
         const Launched r = launch_forward(e, w, b, eps, eps_cos, variant, impl, true);
         ctx->saved_data["squeeze"] = r.squeeze;
-        ctx->saved_data["w_dim"] = (int64_t)w.dim();
-        ctx->saved_data["b_dim"] = (int64_t)b.dim();
+        ctx->saved_data["w_sizes"] = w.sizes().vec();       // one element each, but any shape: the gradient comes back in it
+        ctx->saved_data["b_sizes"] = b.sizes().vec();
         ctx->save_for_backward({r.dE, r.sc});
         at::Tensor loss = r.sc[0];
         return r.squeeze ? loss[0] : loss;
@@ -116,8 +136,8 @@ struct GE2ELossNode : public torch::autograd::Function<GE2ELossNode> {
               "ge2e_scale_grads");
         if (need_e && ctx->saved_data["squeeze"].toBool()) gE = gE[0];
         at::Tensor gw, gb;
-        if (need_w) gw = ctx->saved_data["w_dim"].toInt() == 0 ? gwb[0] : gwb.slice(0, 0, 1);
-        if (need_b) gb = ctx->saved_data["b_dim"].toInt() == 0 ? gwb[1] : gwb.slice(0, 1, 2);
+        if (need_w) gw = gwb[0].reshape(ctx->saved_data["w_sizes"].toIntVector());
+        if (need_b) gb = gwb[1].reshape(ctx->saved_data["b_sizes"].toIntVector());
         return {gE, gw, gb, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
@@ -143,6 +163,7 @@ at::Tensor ge2e_loss_forward_only(const at::Tensor& e, const at::Tensor& w, cons
 
 TORCH_LIBRARY(ge2e_amd, m) {
     m.def("loss(Tensor e, Tensor w, Tensor b, float eps, float eps_cos, int variant, int impl) -> Tensor");
+    m.def("cached_workspace(Tensor like) -> Tensor", cached_workspace);
 }
 TORCH_LIBRARY_IMPL(ge2e_amd, Autograd, m) { m.impl("loss", ge2e_loss_autograd); }
 TORCH_LIBRARY_IMPL(ge2e_amd, CUDA, m) { m.impl("loss", ge2e_loss_forward_only); }

@@ -714,12 +714,28 @@ def _cpp_loss_op():
     if not _cpp_node["tried"]:
         _cpp_node["tried"] = True
         import os
+        import warnings
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libge2e_torch.so")
-        if os.path.exists(path):
+        # libge2e_torch.so is linked (rpath $ORIGIN) against the IN-TREE libge2e_hip.so: with GE2E_HIP_LIB pointing somewhere
+        # else (A/B runs of two libraries) the node would launch the wrong library's kernels -- the Python node is used then
+        if os.path.exists(path) and not os.environ.get("GE2E_HIP_LIB"):
             _lib.load()                                   # the core library first: missing -> the loud error, not a dlopen one
-            torch.ops.load_library(path)
-            _cpp_node["op"] = torch.ops.ge2e_amd.loss
+            try:
+                torch.ops.load_library(path)
+                _cpp_node["op"] = torch.ops.ge2e_amd.loss
+            except (OSError, RuntimeError) as ex:         # built against another torch / a relinked core library
+                warnings.warn(f"libge2e_torch.so could not be loaded ({str(ex)[:120]}); using the Python autograd node "
+                              f"(same launches).  Rebuild with `python -m speaker_embedding_ge2e_loss_amd.build --force`.")
     return _cpp_node["op"] if _cpp_node["enabled"] else None
+
+
+def cpp_node_workspace(like: torch.Tensor):
+    """The workspace the C++ autograd node keeps for `like`'s device and the current stream (None when it has none, or when
+    the node is not in use): for `workspace_fallback_count`."""
+    if _cpp_loss_op() is None:
+        return None
+    ws = torch.ops.ge2e_amd.cached_workspace(like)
+    return ws if ws.numel() > 0 else None
 
 
 def use_cpp_autograd(enabled: bool) -> None:

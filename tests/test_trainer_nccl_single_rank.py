@@ -64,7 +64,15 @@ def test_auto_impl_beside_rccl_allreduce():
             tr.step(mel)
         torch.cuda.synchronize()
         times, aborted = [], 0
-        base = GF.workspace_fallback_count(GF._ws_cache[(dev.index, GF._stream_ptr(mel))])
+
+        def step_workspace():
+            # DPTrainer's default path goes GE2ELoss.forward -> GF.ge2e_loss -> the C++ autograd node, which keeps its OWN
+            # per-(device, stream) workspace cache; the Python node uses GF._ws_cache.  Read the one that ran the step.
+            ws = GF.cpp_node_workspace(mel)
+            return ws if ws is not None else GF._ws_cache[(dev.index, GF._stream_ptr(mel))]
+
+        assert GF.cpp_node_workspace(mel) is not None or GF._cpp_loss_op() is None
+        base = GF.workspace_fallback_count(step_workspace())
         for _ in range(200):
             t0 = time.perf_counter()
             lv = tr.step(mel)
@@ -73,8 +81,7 @@ def test_auto_impl_beside_rccl_allreduce():
             assert bool(torch.isfinite(lv))
             # TeamCtl.fallbacks of THIS stream's workspace: calls whose abort word was up (the block cleans itself after
             # every call, the count survives)
-            ws = GF._ws_cache[(dev.index, GF._stream_ptr(mel))]
-            aborted = GF.workspace_fallback_count(ws) - base
+            aborted = GF.workspace_fallback_count(step_workspace()) - base
         med, p95, worst = float(np.median(times)), float(np.percentile(times, 95)), float(np.max(times))
         print(f"single-rank RCCL trainer step: median {med * 1e6:.0f} us, p95 {p95 * 1e6:.0f} us, worst {worst * 1e6:.0f} us, "
               f"aborts {aborted}")
