@@ -62,6 +62,17 @@ __device__ __forceinline__ void split4_scaled_u(const float4& x, float sc_unifor
     hi = __builtin_bit_cast(h4, h);
     lo = __builtin_bit_cast(h4, l);
 }
+// fma(float(low / high half of a packed fp16 pair), b, c) in one instruction
+__device__ __forceinline__ float fma_mix_lo(unsigned hpack, float b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpack), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned hpack, float b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpack), "v"(b), "v"(c));
+    return d;
+}
 // the two halves of split4_scaled_u as separate steps (callers interleave several vectors' chains)
 __device__ __forceinline__ void split4_scaled_hi_u(const float4& x, float sc_uniform, h4& hi) {
     uint2 h;

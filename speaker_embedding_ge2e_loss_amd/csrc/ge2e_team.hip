@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             cj_cur = has_spk ? scale4(c, rn) : zero4();
             rn_cur = rn; kap_cur = kap;
             h4 hi, lo;
-            split4(scale4(cj_cur, kSplitScale), hi, lo);
+            split4_scaled(cj_cur, kSplitScale, hi, lo);
             {   // fragment-major form for X: one 1-KB block per (slot tile, hi / lo, 32-column K-step) holding the 64 lanes'
                 // 16-byte MFMA fragments in lane order (lane = 16 q + slot-in-tile), so that a consumer's load instruction
                 // reads 1 KB contiguously.  (As plain row-major rows every load instruction fetched 16 x 64 bytes, the
@@ -353,10 +353,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2)
                                 mfma16x3(acc, ga[i][s2][0], ga[i][s2][1], gb[rb & 1][s2][0], gb[rb & 1][s2][1]);
-                            held[i][rb] = make_float4(fmaf((float)eh[i][0], rc.y, fmaf((float)el[i][0], rc.y, acc[0] * rc.x)),
-                                                      fmaf((float)eh[i][1], rc.y, fmaf((float)el[i][1], rc.y, acc[1] * rc.x)),
-                                                      fmaf((float)eh[i][2], rc.y, fmaf((float)el[i][2], rc.y, acc[2] * rc.x)),
-                                                      fmaf((float)eh[i][3], rc.y, fmaf((float)el[i][3], rc.y, acc[3] * rc.x)));
+                            // ra acc + c1 (e-hat hi + e-hat lo): the fp16 image values enter a mixed-precision FMA directly
+                            // (v_fma_mix_f32: the same fma(float(h), c1, t) as a convert and an fmaf, in one instruction)
+                            const uint2 ehb = __builtin_bit_cast(uint2, eh[i]), elb = __builtin_bit_cast(uint2, el[i]);
+                            held[i][rb] = make_float4(fma_mix_lo(ehb.x, rc.y, fma_mix_lo(elb.x, rc.y, acc[0] * rc.x)),
+                                                      fma_mix_hi(ehb.x, rc.y, fma_mix_hi(elb.x, rc.y, acc[1] * rc.x)),
+                                                      fma_mix_lo(ehb.y, rc.y, fma_mix_lo(elb.y, rc.y, acc[2] * rc.x)),
+                                                      fma_mix_hi(ehb.y, rc.y, fma_mix_hi(elb.y, rc.y, acc[3] * rc.x)));
                         }
                         if (NTI == 2) T2_PAIR_LINES(held[0][rb], held[1][rb]);
                         __builtin_amdgcn_sched_barrier(0);   // one row block at a time (registers)
@@ -434,7 +437,13 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             for (int i = 0; i < MR; ++i) {
                 if (i < M) {
                     const float sc = lane_get(rs_l, scatter_lane(i));
-                    if (dact) put_split4(ETh, ETl, et_off<D>(rbase + i, d4), scale4(rowv[i], sc));
+                    if (dact) {     // scale and split fused (v_fma_mixlo / mixhi_f16: 8 instructions per float4 instead of 16)
+                        h4 hi4, lo4;
+                        split4_scaled_u(rowv[i], sc, hi4, lo4);
+                        const int eo = et_off<D>(rbase + i, d4);
+                        *reinterpret_cast<h4*>(ETh + eo) = hi4;
+                        *reinterpret_cast<h4*>(ETl + eo) = lo4;
+                    }
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time (registers)
             }
@@ -519,9 +528,9 @@ _Pragma("unroll")                                                               
         // ===== X(cur): X[r][slot] over this wave's K half -> LDS (fragments of the next row block under the MFMAs) ==
 #define T2_X_LOAD(T_)                                                                                     \
     do {                                                                                                  \
-        const int xo_ = (16 * ((T_) / NCH) + l15) * P + (((4 * (khX * NCH + (T_) % NCH) + q) ^ fx) << 3); \
-        fb[(T_) & 1][0] = frag_row(ETh + xo_);                                                            \
-        fb[(T_) & 1][1] = frag_row(ETl + xo_);                                                            \
+        const _Float16* const pp_ = ETh + xs[(T_) % NCH] + 16 * ((T_) / NCH) * P;                         \
+        fb[(T_) & 1][0] = frag_row(pp_);                                                                  \
+        fb[(T_) & 1][1] = frag_row(pp_ + RT * P);                                                         \
     } while (0)
 #define T2_X_STORE(RB_)                                                                       \
     *reinterpret_cast<float4*>(XBk + (16 * (RB_) + l15) * XP + 16 * tX + 4 * q) =             \
@@ -532,6 +541,8 @@ _Pragma("unroll")                                                               
             float* const XBk = khX ? XB1 : XB0;                                                                            \
             const int fx = (4 * (l15 & 3) + ((4 - (l15 >> 2)) & 3)) & ((D % 128 == 0) ? 15 : 7);   /* et_off's f of rows 16 rb + l15 */ \
             h8 fb[2][2];            /* [K-step parity][hi, lo]: the next K-step's row fragments are requested under this one's MFMAs */ \
+            int xs[NCH];            /* one lane offset per K-step (the swizzle has period 16 in the row); row block + lo image: immediates */ \
+            _Pragma("unroll") for (int s2 = 0; s2 < NCH; ++s2) xs[s2] = l15 * P + (((4 * (khX * NCH + s2) + q) ^ fx) << 3); \
             f32x4 acc[2] = {acc_zero4(), acc_zero4()};                                                                     \
             T2_X_LOAD(0);                                                                                                  \
 _Pragma("unroll")                                                                                                          \
@@ -647,6 +658,7 @@ _Pragma("unroll")                                                               
             for (int j = 0; j < 4; ++j) ownj[j] = own_lane && jo == j;
             float per, ad0, coefsum, db_row;
             float gv[16];
+            float gsc = 0.f, own_un = 0.f;     // per-lane scale of the G image entries; factor that puts o on the unscaled side
             if (!CONTRAST) {
                 // the row maximum over the OTHER speakers' columns (the own column enters with its leave-one-out value)
                 float xm0 = ownj[0] ? x[1] : x[0], xm1 = ownj[1] ? x[0] : x[1], xm2 = ownj[2] ? x[3] : x[2], xm3 = ownj[3] ? x[2] : x[3];
@@ -687,9 +699,8 @@ _Pragma("unroll")                                                               
                 const float rzv = rv ? rz : 0.f;
                 coefsum = fmaf(ap * kSplitInv2, rzv, ad0 * cosd);     // sum_k dL/dS_k c0_k
                 db_row = fmaf(zp, rzv, ad0);
-                const float gs = rzv * kSplitScale;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) gv[j] *= gs;
+                gsc = rzv * kSplitScale;                       // the G image holds gv * gsc (fused into the split below)
+                own_un = z;                                    // own column: o * z * (rz 2^8) = o 2^8 (1 +- 2^-23)
             } else {
                 float best = -INFINITY, bx = 0.f; int besti = 0x7fffffff;
 #pragma unroll
@@ -710,7 +721,9 @@ _Pragma("unroll")                                                               
                 coefsum = fmaf(gn, bx * kSplitInv2, ad0 * cosd);
                 db_row = gn + ad0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gv[j] = (((sb + j) & (NC - 1)) == besti && vld(j)) ? gn * kSplitScale : 0.f;
+                for (int j = 0; j < 16; ++j) gv[j] = (((sb + j) & (NC - 1)) == besti && vld(j)) ? gn : 0.f;
+                gsc = kSplitScale;
+                own_un = 1.0f;
             }
             if (rv && own_lane) {
                 loss_acc = per;
@@ -743,14 +756,18 @@ _Pragma("unroll")                                                               
                     *reinterpret_cast<float2*>(RS + r * 8 + 4) =
                         make_float2(rne * (w * kSplitInv2),                         // ra: of the gE accumulator (2^16)
                                     c1 * kSplitInv);                                // c1: of the e-hat image value (2^8)
-                const float og = o * kSplitScale;
+                const float og = o * own_un;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gv[j] = ownj[j] ? og : gv[j];
                 if (rv) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        put_split4(Gh, Gl, g_off(r, (sb + 4 * jj) & (NC - 1)),
-                                   make_float4(gv[4 * jj], gv[4 * jj + 1], gv[4 * jj + 2], gv[4 * jj + 3]));
+                    for (int jj = 0; jj < 4; ++jj) {
+                        h4 gh4, gl4;
+                        split4_scaled(make_float4(gv[4 * jj], gv[4 * jj + 1], gv[4 * jj + 2], gv[4 * jj + 3]), gsc, gh4, gl4);
+                        const int go = g_off(r, (sb + 4 * jj) & (NC - 1));
+                        *reinterpret_cast<h4*>(Gh + go) = gh4;
+                        *reinterpret_cast<h4*>(Gl + go) = gl4;
+                    }
                 }
             }
         }

@@ -144,6 +144,78 @@ __global__ __launch_bounds__(512) void k_read(const float* buf, size_t span_byte
     if (acc[0] + acc[1] == 12345.678f) sink[0] = acc[0];
 }
 
+// sequential streams, the team kernels' pattern: workgroup b takes the 64-KB chunks b, b + grid, b + 2 grid, ... of the buffer
+// (wave w of it the 8-KB piece w: eight 1-KB rows); MODE 0: nt loads, MODE 1: nt stores
+template <int MODE>
+__global__ __launch_bounds__(512) void k_stream(float* buf, size_t span_bytes, float* sink, int iters) {
+    const size_t nchunks = span_bytes >> 16;
+    f32x4 acc = {};
+    const unsigned lane_off = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 8192;
+    const u32x4 val = {1u, 2u, 3u, (unsigned)threadIdx.x};
+    for (int it = 0; it < iters; ++it) {
+        const size_t c = ((size_t)blockIdx.x + (size_t)it * gridDim.x) % nchunks;
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(buf) + (c << 16), 0, 65536, 0x00020000);
+        if (MODE == 0) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(r2, lane_off + 1024u * i, 0, 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc[0] += __uint_as_float(v[i][0]); acc[1] += __uint_as_float(v[i][3]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(val, r2, lane_off + 1024u * i, 0, 2);
+        }
+    }
+    if (acc[0] + acc[1] == 12345.678f) sink[0] = acc[0];
+}
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512) void k_mfma32(float* sink, int iters) {
+    h8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x - i)); }
+    f32x16 acc[2] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i];
+    if (s == 12345.678f) sink[0] = s;
+}
+__global__ __launch_bounds__(512) void k_valu_mix(float* sink, int iters, float a) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_fma_mix_f32 %0, %0, %1, %1 op_sel_hi:[1,0,0]" : "+v"(x[i]) : "v"(a));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    if (s == 12345.678f) sink[0] = s;
+}
+__global__ __launch_bounds__(512) void k_valu_dpp(float* sink, int iters) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 // ---- host: run an activity for `secs`, sample rocm-smi meanwhile -----------------------------------------------------------
 static bool smi(double& watts, double& mhz) {
     FILE* f = popen("/opt/rocm/bin/rocm-smi --showclocks --showpower -d 0 2>/dev/null", "r");
@@ -219,12 +291,18 @@ int main(int argc, char** argv) {
       report("v_fma_f32, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu_cvt, dim3(cus), dim3(512), 0, 0, sink, IT, 1.0001f); });
       report("v_cvt_pk_f16_f32, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu_mix, dim3(cus), dim3(512), 0, 0, sink, IT, 1.0001f); });
+      report("v_fma_mix_f32, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu_dpp, dim3(cus), dim3(512), 0, 0, sink, IT); });
+      report("v_add_f32_dpp, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_exp, dim3(cus), dim3(512), 0, 0, sink, IT / 2); });
       report("v_exp_f32, 2 waves per SIMD", r, waves * (IT / 2) * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma<4>, dim3(cus), dim3(512), 0, 0, sink, IT / 2); });
       report("mfma 16x16x32 f16, 1 wave per SIMD", r, cus * 4.0 * (IT / 2) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma<8>, dim3(cus), dim3(512), 0, 0, sink, IT / 4); });
       report("mfma 16x16x32 f16, 2 waves per SIMD", r, cus * 8.0 * (IT / 4) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma32, dim3(cus), dim3(512), 0, 0, sink, IT / 8); });
+      report("mfma 32x32x16 f16, 2 waves per SIMD", r, cus * 8.0 * (IT / 8) * 8.0, "MFMA", 1e9, "nJ per MFMA (32.8 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_lds, dim3(cus), dim3(512), 65536, 0, sink, IT / 2); });
       report("ds_read_b128, 2 waves per SIMD", r, waves * (IT / 2) * 16.0 * 1024.0, "B", 1e12, "pJ per LDS byte"); }
     { const size_t span = (size_t)1 << 21;       // 2 MiB: stays in every XCD's L2
@@ -235,5 +313,9 @@ int main(int argc, char** argv) {
       report("16-B loads, 128 MiB span (Infinity Cache)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_read<2>, dim3(cus), dim3(512), 0, 0, buf, big, sink, 400); });
       report("16-B nt loads, 8 GiB span (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_stream<0>, dim3(cus), dim3(512), 0, 0, buf, big, sink, 400); });
+      report("sequential 64-KB chunks, nt loads (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_stream<1>, dim3(cus), dim3(512), 0, 0, buf, big, sink, 400); });
+      report("sequential 64-KB chunks, nt stores (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
     return 0;
 }
