@@ -132,3 +132,19 @@ class SpeakerBatchLoader:
         perm: List[int] = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
         for i in range(0, n - self.batch_size + 1, self.batch_size):
             yield self.sampler.batch(perm[i:i + self.batch_size])
+
+
+def get_train_test_data_loader(hp):
+    """The reference's factory of the same name (s1:80-107): ``(train_loader, test_loader)`` built from ``hp`` alone --
+    the ``sv_*.npy`` folders ``hp.m_ge2e.tt_data.train_spects_path`` / ``test_spects_path`` under
+    ``hp.general.project_root``, ``training_N`` / ``test_N`` speakers per batch with ``training_M`` / ``test_M`` utterances
+    of ``min_train_utter_len`` / ``min_test_utter_len`` frames, the training loader shuffled, both ``drop_last``.  The
+    loaders yield (N, M, frames, mels) float32 batches that are already on ``hp.general.device`` (the reference's yield
+    float64 host tensors that s4:170 / s5:33 move and s2:28 casts); they are re-iterable, one pass per epoch."""
+    root = hp.general.project_root
+    dev = hp.general.device
+    train_store = SpectrogramStore.from_dir(os.path.join(root, hp.m_ge2e.tt_data.train_spects_path), dev)
+    test_store = SpectrogramStore.from_dir(os.path.join(root, hp.m_ge2e.tt_data.test_spects_path), dev)
+    train_loader = GE2EBatchSampler.from_hp(train_store, hp, training=True).loader(hp.m_ge2e.training_N, shuffle=True)
+    test_loader = GE2EBatchSampler.from_hp(test_store, hp, training=False).loader(hp.m_ge2e.test_N, shuffle=False)
+    return train_loader, test_loader

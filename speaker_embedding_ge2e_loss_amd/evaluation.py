@@ -49,12 +49,15 @@ def eer_from_sim(sim_matrix: torch.Tensor, thresholds=THRESHOLDS, normalized: bo
 
 
 def calculate_ERR(model, hp, N: int = 4, M: int = 16, test_loader=None, verbose: bool = True):
-    """s5:16-100.  ``test_loader`` yields (N,M,T,F) mel batches; the reference builds it from its
-    spectrogram folders (s5:21, s1 -- outside this path), here the caller passes it.
+    """s5:16-100, the reference's signature: ``calculate_ERR(model, hp, N, M)`` writes N, M into ``hp.m_ge2e.test_N`` /
+    ``test_M`` (s5:17-18) and builds the test loader from ``hp`` (s5:21) -- here ``data.get_train_test_data_loader``'s
+    second result: the ``sv_*.npy`` folder ``hp.m_ge2e.tt_data.test_spects_path`` resident in HBM, batches gathered by one
+    kernel.  ``test_loader`` (an iterable of (N,M,T,F) mel batches) replaces that default for callers that have their own.
     Prints the reference's result line per batch and returns the results (the reference returns None)."""
-    if test_loader is None:
-        raise ValueError("pass test_loader: an iterable of (N,M,frames,mels) batches (s1's loader is out of scope)")
     hp.m_ge2e.test_N, hp.m_ge2e.test_M = N, M  # s5:17-18
+    if test_loader is None:
+        from .data import get_train_test_data_loader
+        _, test_loader = get_train_test_data_loader(hp)   # s5:21
     total = N * M
     results = []
     with torch.no_grad():

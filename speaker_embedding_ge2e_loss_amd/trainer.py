@@ -227,3 +227,52 @@ class DPTrainer:
         """s4:261-264: only the encoder group's lr is halved; the (w,b) group keeps its own."""
         self.lr = self.lr / 2
         self.optimizer.param_groups[0]["lr"] = self.lr
+
+
+class TrainEmbedModel:
+    """The reference's training object (s4:19-59, :137-276) over ``DPTrainer``: same constructor argument (``hp``), same
+    attributes (``model``, ``ge2e_loss``, ``optimizer``, ``lr``, ``train_loader``, ``test_loader``, ``train_losses``,
+    ``test_losses``, ``total_utterances``, ``hp``) and ``train_model(lr_reduce, epoch_print, dot_print)`` returning
+    ``(model, train_losses, test_losses)`` -- so ``train_embedding_model.py:33-36`` runs against this package by changing
+    its import.  Everything is built from ``hp``: the encoder (``SpeakerEncoder.from_hp``, optionally restored from
+    ``hp.m_ge2e.model_path``), the HIP loss module, the two-group SGD, the resident-store loaders
+    (``data.get_train_test_data_loader``) and the checkpoint folder.  ``train_model`` is ``DPTrainer.fit`` with the
+    reference's schedule read from ``hp.m_ge2e`` (epochs, checkpoint interval, best-weights rule); under
+    ``torch.distributed`` every rank trains on its own batches and the gradients are averaged in one bucket per step."""
+
+    def __init__(self, hp, variant: str = "softmax", fused_tail: bool = False):
+        import os
+        from .encoder import SpeakerEncoder
+        from .loss import GE2ELoss
+        from .data import get_train_test_data_loader
+        self.hp = hp
+        self.model = SpeakerEncoder.from_hp(hp, normalize=not fused_tail)                    # s4:21
+        self._restore = None
+        if getattr(hp.m_ge2e, "restore_existing_model", False):                             # s4:24-30
+            self._restore = os.path.join(hp.general.project_root, hp.m_ge2e.model_path)
+            self.model.load_state_dict(torch.load(self._restore, map_location=hp.general.device))
+            print(f"Pre-trained model loaded {self._restore}")
+        self.ge2e_loss = GE2ELoss(hp, variant=variant)                                       # s4:33
+        self.lr = hp.m_ge2e.lr                                                               # s4:41
+        self.trainer = DPTrainer(self.model, self.ge2e_loss, lr=self.lr, fused_tail=fused_tail)
+        self.optimizer = self.trainer.optimizer                                              # s4:35-42
+        self.train_loader, self.test_loader = get_train_test_data_loader(hp)                 # s4:45
+        self.checkpoint_dir = None
+        if getattr(hp.m_ge2e, "checkpoint_dir", None) is not None:                           # s4:48-49
+            self.checkpoint_dir = os.path.join(hp.general.project_root, hp.m_ge2e.checkpoint_dir)
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+        self.train_losses, self.test_losses = [], []                                         # s4:52-53
+        self.total_utterances = hp.m_ge2e.training_N * hp.m_ge2e.training_M                  # s4:56
+
+    def train_model(self, lr_reduce: int = 2000, epoch_print: int = 100, dot_print: int = 10):
+        """s4:137-276.  ``dot_print`` only paces the reference's progress dots; nothing is printed per epoch here."""
+        m = self.hp.m_ge2e
+        model, tr, te = self.trainer.fit(
+            self.train_loader, m.training_epochs, test_batches=self.test_loader, lr_reduce=lr_reduce, epoch_print=epoch_print,
+            checkpoint_dir=self.checkpoint_dir, checkpoint_interval=getattr(m, "checkpoint_interval", 200),
+            save_best_weights=bool(getattr(m, "save_best_weights", False)),
+            min_test_loss=float(getattr(m, "min_test_loss", float("inf"))))
+        self.lr = self.trainer.lr
+        self.train_losses += tr
+        self.test_losses += te
+        return model, self.train_losses, self.test_losses

@@ -99,3 +99,20 @@ def test_eer_counts_ties_nan_and_random_tables():
         for t in range(T):
             acc = S[b] > thr[t]
             assert got[b, t, 0] == int((acc & ~own).sum()) and got[b, t, 1] == int((acc & own).sum()), (b, t)
+
+
+def test_entry_points_have_the_reference_signatures():
+    """s5:16 `calculate_ERR(model, hp, N=4, M=16)` and s4:19 / s4:137 `TrainEmbedModel(hp).train_model(lr_reduce=2000,
+    epoch_print=100, dot_print=10)`: positional order and defaults as in the reference, so its scripts can switch imports."""
+    import inspect
+    from speaker_embedding_ge2e_loss_amd.evaluation import calculate_ERR
+    from speaker_embedding_ge2e_loss_amd.trainer import TrainEmbedModel
+    from speaker_embedding_ge2e_loss_amd.data import get_train_test_data_loader
+    ps = list(inspect.signature(calculate_ERR).parameters.values())
+    assert [p.name for p in ps[:4]] == ["model", "hp", "N", "M"] and ps[2].default == 4 and ps[3].default == 16
+    assert all(p.default is not inspect.Parameter.empty for p in ps[2:])
+    pi = list(inspect.signature(TrainEmbedModel.__init__).parameters.values())
+    assert [p.name for p in pi[:2]] == ["self", "hp"] and all(p.default is not inspect.Parameter.empty for p in pi[2:])
+    pt = inspect.signature(TrainEmbedModel.train_model).parameters
+    assert [(n, p.default) for n, p in list(pt.items())[1:]] == [("lr_reduce", 2000), ("epoch_print", 100), ("dot_print", 10)]
+    assert list(inspect.signature(get_train_test_data_loader).parameters) == ["hp"]

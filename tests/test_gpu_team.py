@@ -7,7 +7,7 @@ import torch
 
 from conftest import rel_fro
 from oracle import ge2e_oracle as orc
-from test_gpu_parity import run_hip
+from test_gpu_parity import check, run_hip
 import bench
 
 BENCH_B = bench.CONFIGS["cfg2"]["B"]      # batches per launch of the metric config's bench line
@@ -45,6 +45,7 @@ def test_many_batches_per_team_full_size(GF, impl):
         assert np.allclose(ot["loss"][i], ref["loss"], rtol=2e-5)
         assert rel_fro(ot["dE"][i], ref["dE"]) < 2e-5
         assert np.allclose(ot["per"][i], ref["per"], rtol=1e-4, atol=1e-4)
+        check({k: v[i] for k, v in ot.items()}, ref, impl, f"batch {i}", strict=True)
 
 
 @pytest.mark.parametrize("shape", [(40, 23, 7, 128), (70, 9, 5, 64), (3, 32, 16, 64), (33, 64, 2, 192), (5, 17, 4, 256)])
@@ -91,6 +92,8 @@ def test_small_d_full_members(GF, shape, impl):
     assert np.allclose(o["dw"], ref["dw"], rtol=1e-4, atol=1e-4)
     for i in range(B):
         assert rel_fro(o["dE"][i], ref["dE"][i]) < 2e-5, i
+    if N == 64 and M == 10:      # the metric's (N, M): the flat gate of the BASELINE configs (db atol 1e-4, dw rtol + 1e-5)
+        check(o, ref, impl, f"{shape}/{impl}", strict=True)
 
 
 def test_fallback_when_no_team_forms(GF):
