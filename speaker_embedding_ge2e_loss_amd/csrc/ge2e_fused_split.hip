@@ -107,7 +107,8 @@ __device__ __forceinline__ float4 get_join4(const _Float16* hi_img, const _Float
 
 }  // namespace
 
-size_t fused_split_lds_bytes(int D) {
+size_t fused_split_lds_bytes(int Dc) {
+    const int D = (Dc + 63) / 64 * 64;   // the kernel's column count: the caller's D padded to a multiple of 64
     const int PH = D + 16;
     return (size_t)4 * 64 * PH * 2 + (size_t)2 * 64 * GP * 2 + (size_t)(TR * 8 + NC * 4 + 32) * sizeof(float);
 }
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     constexpr int P = D + 4;    // fp32 pitch of the gC staging that reuses the ET images in finalize
     constexpr int PH = D + 16;  // fp16 image pitch: rows 8 banks apart (mod 64) -> neither the b128 row reads nor the
                                 // 4-row x 32-byte transposing reads collide (D + 8 cost 39 % of the LDS cycles in conflicts)
-    constexpr unsigned ROWB = D * 4;  // bytes per embedding row
+    constexpr unsigned ROWB = D * 4;  // bytes per row of the WORKSPACE and LDS layouts (D = 64 NCH columns)
+    // The caller's D may be smaller than 64 NCH (any multiple of 4 up to 256: AUTO pads it here instead of falling through to
+    // the VALU kernel): E and dE rows are DG floats apart, columns DG .. D - 1 are read as zeros (out-of-range buffer
+    // offsets) and never stored -- zero columns change neither a dot product nor a norm.
+    const int DG = p.D;
+    const unsigned ROWBG = (unsigned)DG * 4u;
     _Float16* const CHh = reinterpret_cast<_Float16*>(smem_f);
     _Float16* const CHl = CHh + NC * PH;
     _Float16* const ETh = CHl + NC * PH;
@@ -166,8 +172,9 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     const bool contrast = p.variant == 1;
     const bool want_grad = p.dE != nullptr;
 
-    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                   // one row per wave
-    const unsigned vtile = (unsigned)((8 * wid + sub) * D + 4 * l16) * 4u;  // 4 rows per wave, + g*4 rows
+    const unsigned vrow = dact ? (unsigned)d4 * 4u : OOB;                   // one row per wave (workspace rows: D columns)
+    const unsigned vrowg = d4 < DG ? (unsigned)d4 * 4u : OOB;               // ... of E: DG columns
+    const unsigned vtile = (unsigned)((8 * wid + sub) * DG + 4 * l16) * 4u; // 4 rows per wave, + g*4 rows
 
     GE2E_PROF_DECL(10)
     bool have_sums = false;   // speaker sums of the current batch already sit in the workspace
@@ -180,11 +187,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         const int wid = wid_o, M = m_o, N = n_o, NM = N * M, spt = spt_o, ntiles = nt_o, tid = tid_o;
         const int kh = wid >> 2, sl = wid & 3;
         const bool slice_on = 64 * sl < D;
-        const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * D, (unsigned)NM * ROWB);
+        const __amdgpu_buffer_rsrc_t rsE = make_rsrc(p.E + (size_t)bi * NM * DG, (unsigned)NM * ROWBG);
         const __amdgpu_buffer_rsrc_t rsE2s = rsE;
         const __amdgpu_buffer_rsrc_t rsE3 = rsE;
-        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * D : nullptr,
-                                                      want_grad ? (unsigned)NM * ROWB : 0u);
+        const __amdgpu_buffer_rsrc_t rsG = make_rsrc(want_grad ? p.dE + (size_t)bi * NM * DG : nullptr,
+                                                      want_grad ? (unsigned)NM * ROWBG : 0u);
 
         // ================= sweep 1: speaker sums -> unit centroid images =====================
         // Each wave owns a contiguous eighth of the speakers.  The first batch of this workgroup
@@ -206,12 +213,12 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         };
         if (!have_sums) {
             const int nr = nr_w;
-            const unsigned base = (unsigned)(jb * M) * ROWB;
+            const unsigned base = (unsigned)(jb * M) * ROWBG;
             constexpr int RING = 16;
             float4 ring[RING];
 #pragma unroll
             for (int u = 0; u < RING; ++u)
-                ring[u] = bload4<GE2E_AUX_E1>(rsE, vrow, base + (unsigned)min(u, max(nr - 1, 0)) * ROWB);
+                ring[u] = bload4<GE2E_AUX_E1>(rsE, vrowg, base + (unsigned)min(u, max(nr - 1, 0)) * ROWBG);
             float4 s = zero4();
             int cnt = 0, j = jb;
             for (int rb = 0; rb < nr; rb += RING) {
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         s.x += ring[u].x; s.y += ring[u].y; s.z += ring[u].z; s.w += ring[u].w;
                         if (++cnt == M) { finish_speaker(j, s); s = zero4(); cnt = 0; ++j; }
                     }
-                    ring[u] = bload4<GE2E_AUX_E1>(rsE, vrow, base + (unsigned)min(row + RING, max(nr - 1, 0)) * ROWB);
+                    ring[u] = bload4<GE2E_AUX_E1>(rsE, vrowg, base + (unsigned)min(row + RING, max(nr - 1, 0)) * ROWBG);
                 }
             }
         } else {
@@ -261,11 +268,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     do {                                                                                    \
         const int j0_ = (T) * spt;                                                          \
         const int nrows_ = min(spt, N - j0_) * M;                                           \
-        const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                    \
+        const unsigned tb_ = (unsigned)(j0_ * M) * ROWBG;                                   \
         _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                     \
             const unsigned vo_ = (8 * wid + 4 * g + sub < nrows_) ? vtile : OOB;            \
             _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                 \
-                v[g][c] = bload4<AUX>(rsE2s, vo_, tb_ + (unsigned)(4 * g) * ROWB + 256u * c); \
+                v[g][c] = bload4<AUX>(rsE2s, 4 * l16 + 64 * c < DG ? vo_ : OOB, tb_ + (unsigned)(4 * g) * ROWBG + 256u * c); \
         }                                                                                   \
     } while (0)
 
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
         float4 ev[4][2];
         // raw rows in the epilogue's layout: row 32 kh + 8 g + 4 h + (lane & 3), columns 64 sl + 32 b + 4 (l31 >> 2)
         const int pq = lane & 3, cq = l31 >> 2;
-        const unsigned vep = slice_on ? (unsigned)((32 * kh + 4 * h + pq) * D + 64 * sl + 4 * cq) * 4u : OOB;
+        const unsigned vep = slice_on ? (unsigned)((32 * kh + 4 * h + pq) * DG + 64 * sl + 4 * cq) * 4u : OOB;
 #define GE2E_LOAD_TILE3(T)                                                                            \
     do {                                                                                              \
         const int t_ = (T);                                                                           \
@@ -529,26 +536,26 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
     do {                                                                                              \
         const int j0_ = (T) * spt;                                                                    \
         const int nrows_ = min(spt, N - j0_) * M;                                                     \
-        const unsigned tb_ = (unsigned)(j0_ * M) * ROWB;                                              \
+        const unsigned tb_ = (unsigned)(j0_ * M) * ROWBG;                                             \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                 \
             _Pragma("unroll") for (int b = 0; b < 2; ++b)                                             \
-                ev[g][b] = bload4<GE2E_AUX_E3>(rsE3, (32 * kh + 8 * g + 4 * h + pq < nrows_) ? vep : OOB, \
-                                               tb_ + (unsigned)(8 * g) * ROWB + 128u * b);            \
+                ev[g][b] = bload4<GE2E_AUX_E3>(rsE3, (32 * kh + 8 * g + 4 * h + pq < nrows_ && 64 * sl + 32 * b + 4 * cq < DG) ? vep : OOB, \
+                                               tb_ + (unsigned)(8 * g) * ROWBG + 128u * b);           \
     } while (0)
 
         // the next batch of this workgroup: its rows are summed per speaker underneath this sweep
         const int bnext = bi + gridDim.x;
         const bool has_next = bnext < p.B;
-        const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E + (size_t)(has_next ? bnext : bi) * NM * D,
-                                                       has_next ? (unsigned)NM * ROWB : 0u);
+        const __amdgpu_buffer_rsrc_t rsE2 = make_rsrc(p.E + (size_t)(has_next ? bnext : bi) * NM * DG,
+                                                       has_next ? (unsigned)NM * ROWBG : 0u);
         const int nr2 = has_next ? nr_w : 0;
-        const unsigned base2 = (unsigned)(jb * M) * ROWB;
+        const unsigned base2 = (unsigned)(jb * M) * ROWBG;
         float4 ring2[8];
         float4 s2 = zero4();
         int cnt2 = 0, j2 = jb, rb2 = 0;
 #define GE2E_RING2_LOAD(ROW0)                                                                         \
     _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                     \
-        ring2[u] = bload4<GE2E_AUX_E1>(rsE2, vrow, base2 + (unsigned)min((ROW0) + u, max(nr2 - 1, 0)) * ROWB)
+        ring2[u] = bload4<GE2E_AUX_E1>(rsE2, vrowg, base2 + (unsigned)min((ROW0) + u, max(nr2 - 1, 0)) * ROWBG)
         // 8 rows per step; a finished speaker's sum goes to the workspace (wave-uniform branch: at most
         // ceil(8 / M) + 1 stores per step, usually one or none)
 #define GE2E_RING2_STEP()                                                                             \
@@ -612,8 +619,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
                         const float4 e = ev[g][b];
                         const float4 kj = *reinterpret_cast<const float4*>(GCS + j * P + col);
                         // pad rows get an out-of-range offset: the store is dropped, no branch
-                        bstore4<GE2E_AUX_DE>(rsG, rv ? (unsigned)((4 * h + pq) * D + col) * 4u : OOB,
-                                             (unsigned)(r0 + 32 * kh + 8 * g) * ROWB,
+                        bstore4<GE2E_AUX_DE>(rsG, (rv && col < DG) ? (unsigned)((4 * h + pq) * DG + col) * 4u : OOB,
+                                             (unsigned)(r0 + 32 * kh + 8 * g) * ROWBG,
                                 make_float4(x[0] * rs.x + e.x * rs.y + kj.x, x[1] * rs.x + e.y * rs.y + kj.y,
                                             x[2] * rs.x + e.z * rs.y + kj.z, x[3] * rs.x + e.w * rs.y + kj.w));
                     }
@@ -632,11 +639,14 @@ __global__ __launch_bounds__(512, 2) void ge2e_fused_split_kernel(Problem p, Fus
 }
 
 // ---------------------------------------------------------------------------------------------
+// D: any multiple of 4 up to 256 (rows 16-byte aligned); the kernel works on ceil(D / 64) * 64 columns, the rest zeros
+constexpr int pad64(int D) { return (D + 63) / 64 * 64; }
 bool fused_split_supports(int N, int M, int D) {
-    return N >= 1 && N <= 64 && M >= 2 && M <= 64 && D >= 64 && D <= 256 && (D % 64) == 0;
+    return N >= 1 && N <= 64 && M >= 2 && M <= 64 && D >= 4 && D <= 256 && (D % 4) == 0;
 }
 
-FusedWs fused_split_layout(int N, int M, int D) {
+FusedWs fused_split_layout(int N, int M, int Dc) {
+    const int D = pad64(Dc);
     FusedWs L;
     int spt = TR / M;
     if (spt > MAX_SPT) spt = MAX_SPT;
@@ -676,7 +686,7 @@ static hipError_t launch_nch(const Problem& p, const FusedWs& L, size_t lds, hip
 hipError_t launch_fused_split(const Problem& p, hipStream_t stream) {
     const size_t lds = fused_split_lds_bytes(p.D);
     const FusedWs L = fused_split_layout(p.N, p.M, p.D);
-    switch (p.D / 64) {
+    switch (pad64(p.D) / 64) {
         case 1: return launch_nch<1>(p, L, lds, stream);
         case 2: return launch_nch<2>(p, L, lds, stream);
         case 3: return launch_nch<3>(p, L, lds, stream);

@@ -54,7 +54,8 @@ constexpr unsigned team_g_bytes(int rt, int D) {     // the G images; between tw
     return 2u * rt * GP * 2 > 8u * D * 4 ? 2u * rt * GP * 2 : 8u * D * 4;
 }
 
-TeamKWs team_layout(int N, int M, int D) {
+TeamKWs team_layout(int N, int M, int Dc) {
+    const int D = (Dc + 63) / 64 * 64;     // the kernels' column count: the caller's D padded to a multiple of 64
     TeamKWs L{};
     L.spm = (N + TEAM - 1) / TEAM;
     L.rt = (L.spm * M + 15) / 16 * 16;
@@ -71,7 +72,7 @@ TeamKWs team_layout(int N, int M, int D) {
 }
 
 bool team_supports(int N, int M, int D) {
-    if (!(N >= 1 && N <= NC && M >= 2 && M <= 16 && D >= 64 && D <= 256 && (D % 64) == 0)) return false;
+    if (!(N >= 1 && N <= NC && M >= 2 && M <= 16 && D >= 4 && D <= 256 && (D % 4) == 0)) return false;
     const TeamKWs L = team_layout(N, M, D);
     if (L.rt > RTMAX || L.lds_bytes > 160 * 1024) return false;
     if (!fused_split_supports(N, M, D)) return false;            // the gated fall-back launch
@@ -96,7 +97,7 @@ static size_t team_fb_bytes(int B, int N, int M, int D) {
 }
 size_t team_workspace_bytes(int B, int N, int M, int D) {
     const TeamKWs L = team_layout(N, M, D);
-    return align_up(L.head_bytes + (size_t)(team_grid(B) / TEAM) * team_exchange(D).stride, 256) + team_fb_bytes(B, N, M, D);
+    return align_up(L.head_bytes + (size_t)(team_grid(B) / TEAM) * team_exchange((D + 63) / 64 * 64).stride, 256) + team_fb_bytes(B, N, M, D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -109,7 +110,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
-    constexpr unsigned ROWB = D * 4;
+    constexpr unsigned ROWB = D * 4;      // bytes per row of the exchange / LDS layouts (D = 64 NCH columns)
+    // The caller's D may be any multiple of 4 up to 64 NCH (AUTO pads it here rather than falling through to the VALU kernel):
+    // rows of E and dE are DG floats apart, columns DG .. D - 1 are read as zeros and never stored.
+    const int DG = RBT ? D : p.D;
+    const unsigned ROWBG = (unsigned)DG * 4u;
     constexpr int NT = 4 * NCH;           // 16-column tiles of a row
     constexpr int NTI = (NT + 7) / 8;     // ... per wave in GE
     constexpr TeamKX XO = team_exchange(D);
@@ -205,11 +210,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     do {                                                                                                 \
         int lq_ = lane;                                                                                  \
         asm volatile("" : "+v"(lq_));                                                                    \
-        const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                  \
+        const unsigned vrow_ = 4 * lq_ < DG ? (unsigned)lq_ * 16u : OOB;                                 \
         const bool on_ = has_spk && (BI) < p.B;                                                          \
-        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * DG, (unsigned)NM * ROWBG); \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
-            rowv[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+            rowv[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWBG); \
     } while (0)
     // lane-derived indices are re-derived inside each phase from an opaque copy of the lane id (kept out of the
     // loop-invariant set: hoisted they spill, and a scratch reload queues behind every VMEM operation in flight)
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
         const bool have_cur = bi < p.B, have_prev = seq > 0;
         if (!have_cur && !have_prev) break;
         const int buf = seq & 1, pbuf = buf ^ 1;
-        const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * D : nullptr,
-                                                       want_grad && have_prev ? (unsigned)NM * ROWB : 0u);
+        const __amdgpu_buffer_rsrc_t rsGp = make_rsrc(want_grad && have_prev ? p.dE + (size_t)(bi - id.nct) * NM * DG : nullptr,
+                                                       want_grad && have_prev ? (unsigned)NM * ROWBG : 0u);
         cj_prev = cj_cur; rn_prev = rn_cur; kap_prev = kap_cur;
         // ===== A1(cur): speaker sum -> unit centroid -> team (row-major, and staged for the k-group form) ==========
         if (have_cur) {
@@ -496,7 +501,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
             GE2E_T2_LANE();                                                                                                \
             const int x8_ = l15 & 7;                                                                                       \
             const float* const kjc_ = KJ + min(NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 4 * q, D - 4);             \
-            const unsigned de0_ = (unsigned)((j0 * M + (NTI == 2 ? x8_ : l15)) * D + (NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 4 * q)) * 4u; \
+            const int dcol_ = NTI == 2 ? 32 * wid + 16 * (l15 >> 3) + 4 * q : 4 * q;   /* + cc: this lane's first column */ \
+            const unsigned de0_ = (unsigned)((j0 * M + (NTI == 2 ? x8_ : l15)) * DG + dcol_) * 4u;                         \
 _Pragma("unroll")                                                                                                          \
             for (int i = 0; i < NTI; ++i) {                                                                                \
                 float4 kjv[RBC];                                                                                           \
@@ -517,10 +523,10 @@ _Pragma("unroll")                                                               
                     if (CT_DE || rb < RBr) {                                                                               \
                         const int rc = NTI == 2 ? 16 * rb + 8 * i : 16 * rb;      /* row and column part that is not in de0_ */ \
                         const int cc = NTI == 2 ? 0 : 16 * T2_DT(i);                                                       \
-                        const bool ok = MEX || (rc + (NTI == 2 ? x8_ : l15) < R_my && T2_DT(i) < NT);                      \
+                        const bool ok = MEX || (rc + (NTI == 2 ? x8_ : l15) < R_my && T2_DT(i) < NT && dcol_ + cc < DG);   \
                         const float4 o = make_float4(held[i][rb].x + kjv[rb].x, held[i][rb].y + kjv[rb].y,                 \
                                                      held[i][rb].z + kjv[rb].z, held[i][rb].w + kjv[rb].w);                \
-                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? de0_ + (unsigned)(rc * D + cc) * 4u : OOB, o);                  \
+                        bstore4<GE2E_T2_DE_AUX>(rsGp, ok ? de0_ + (unsigned)(rc * DG + cc) * 4u : OOB, o);                 \
                     }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                         \
             }                                                                                                              \
@@ -957,7 +963,7 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
 }
 template <int NCH, int MR>
 static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
-    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64) {   // the metric shape: compile-time N, M, trip counts
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64 && p.D == 256) {   // the metric shape: compile-time N, M, D, trip counts
         if (p.dE == nullptr)    // ... and its forward-only form (evaluation: s4:61-110, s5:42-44)
             return p.variant == 1 ? launch_nch<4, 10, 5, true, true>(p, L, stream) : launch_nch<4, 10, 5, false, true>(p, L, stream);
         return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
@@ -972,14 +978,14 @@ hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     if (p.dE == nullptr) {          // similarity + loss only: the pipelined forward kernel (ge2e_team_fwd.hip)
         err = launch_team_fwd(p, L, stream);
     } else if (p.M <= 10) {
-        switch (p.D / 64) {
+        switch ((p.D + 63) / 64) {
             case 1: err = launch_variant<1, 10>(p, L, stream); break;
             case 2: err = launch_variant<2, 10>(p, L, stream); break;
             case 3: err = launch_variant<3, 10>(p, L, stream); break;
             default: err = launch_variant<4, 10>(p, L, stream); break;
         }
     } else {
-        switch (p.D / 64) {
+        switch ((p.D + 63) / 64) {
             case 1: err = launch_variant<1, 16>(p, L, stream); break;
             case 2: err = launch_variant<2, 16>(p, L, stream); break;
             case 3: err = launch_variant<3, 16>(p, L, stream); break;
@@ -995,7 +1001,7 @@ hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     f.cleanup_n16 = (int)(L.head_bytes / 16);
     f.grid_cap = team_fallback_grid(p.B);
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
-                                    align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange(p.D).stride, 256));
+                                    align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange((p.D + 63) / 64 * 64).stride, 256));
     err = launch_fused_split(f, stream);
     if (err != hipSuccess) {
         // The team kernel is queued and NOTHING behind it will clean the control block (tickets, arrival count, hand-off

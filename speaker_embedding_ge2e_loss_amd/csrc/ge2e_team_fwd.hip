@@ -45,7 +45,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
-    constexpr unsigned ROWB = D * 4;
+    const int DG = RBT ? D : p.D;         // the caller's D (a multiple of 4, <= D): rows of E are DG floats apart, the rest zeros
+    const unsigned ROWBG = (unsigned)DG * 4u;
     constexpr TeamKX XO = team_exchange(D);
     constexpr unsigned SC4 = XO.cst[0];   // member scalars [4 batches in flight][8 members][4 floats]: the region the training
                                           // kernel uses for slot scalars (2 KB), which the forward pass keeps in registers
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     do {                                                                                                 \
         int lq_ = lane;                                                                                  \
         asm volatile("" : "+v"(lq_));                                                                    \
-        const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                  \
+        const unsigned vrow_ = 4 * lq_ < DG ? (unsigned)lq_ * 16u : OOB;                                 \
         const bool on_ = has_spk && (BI) < p.B;                                                          \
-        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB); \
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * DG, (unsigned)NM * ROWBG); \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                   \
-            REG[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWB); \
+            REG[i] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && i < M) ? vrow_ : OOB, (unsigned)(j * M + min(i, M - 1)) * ROWBG); \
     } while (0)
 // falling issue priority from barrier to barrier (the remedy of hazard 23 in the tiled contractions: the wave that is behind
 // wins ties) measured -1 % here, as in the training kernel: off unless -DGE2E_TF_WITH_PRIO
@@ -123,15 +124,15 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
 #define GE2E_TF_LOADR_SETUP(BI)                                                                          \
     int lq_ = lane;                                                                                      \
     asm volatile("" : "+v"(lq_));                                                                        \
-    const unsigned vrow_ = 4 * lq_ < D ? (unsigned)lq_ * 16u : OOB;                                      \
+    const unsigned vrow_ = 4 * lq_ < DG ? (unsigned)lq_ * 16u : OOB;                                     \
     const bool on_ = has_spk && (BI) < p.B;                                                              \
-    const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * D, (unsigned)NM * ROWB)
+    const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.E + (size_t)(on_ ? (BI) : 0) * NM * DG, (unsigned)NM * ROWBG)
 #define GE2E_TF_LOADR(REG, I_)                                                                           \
     do {                                                                                                 \
         if ((I_) < MR) {                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             REG[(I_) < MR ? (I_) : 0] = bload4<GE2E_T2_E_AUX>(rs_, (on_ && (I_) < M) ? vrow_ : OOB,      \
-                                                              (unsigned)(j * M + min((I_), M - 1)) * ROWB); \
+                                                              (unsigned)(j * M + min((I_), M - 1)) * ROWBG); \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
@@ -590,7 +591,7 @@ template <int NCH, int MR, int RBT, bool CONTRAST>
 static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>);
     static KernelLaunchState state;
-    const unsigned lds = (unsigned)team_fwd_lds_bytes(L.rt, 64 * NCH);
+    const unsigned lds = (unsigned)team_fwd_lds_bytes(L.rt, 64 * NCH);       // (NCH = ceil(D / 64): padded columns)
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, lds, &nb);
     if (err != hipSuccess) return err;
@@ -607,7 +608,7 @@ static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
 }
 template <int NCH, int MR>
 static hipError_t launch_fwd_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
-    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64)     // the metric shape: compile-time N, M, trip counts
+    if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64 && p.D == 256)     // the metric shape: compile-time N, M, D
         return p.variant == 1 ? launch_fwd_nch<4, 10, 5, true>(p, L, stream) : launch_fwd_nch<4, 10, 5, false>(p, L, stream);
     return p.variant == 1 ? launch_fwd_nch<NCH, MR, 0, true>(p, L, stream) : launch_fwd_nch<NCH, MR, 0, false>(p, L, stream);
 }
@@ -615,14 +616,14 @@ static hipError_t launch_fwd_variant(Problem& p, TeamKWs& L, hipStream_t stream)
 // the team launch of a forward-only call (p.dE == NULL); the caller (launch_team) queues the gated fall-back behind it
 hipError_t launch_team_fwd(Problem& p, TeamKWs& L, hipStream_t stream) {
     if (p.M <= 10) {
-        switch (p.D / 64) {
+        switch ((p.D + 63) / 64) {
             case 1: return launch_fwd_variant<1, 10>(p, L, stream);
             case 2: return launch_fwd_variant<2, 10>(p, L, stream);
             case 3: return launch_fwd_variant<3, 10>(p, L, stream);
             default: return launch_fwd_variant<4, 10>(p, L, stream);
         }
     }
-    switch (p.D / 64) {
+    switch ((p.D + 63) / 64) {
         case 1: return launch_fwd_variant<1, 16>(p, L, stream);
         case 2: return launch_fwd_variant<2, 16>(p, L, stream);
         case 3: return launch_fwd_variant<3, 16>(p, L, stream);

@@ -52,7 +52,8 @@ def test_pipeline_lengths_metric_shape(GF, B):
 
 
 @pytest.mark.parametrize("shape", [(40, 23, 7, 128), (70, 9, 5, 64), (3, 32, 16, 64), (33, 64, 2, 192), (5, 17, 4, 256),
-                                   (66, 16, 4, 64), (9, 40, 16, 128), (35, 57, 9, 256), (4, 64, 10, 64)])
+                                   (66, 16, 4, 64), (9, 40, 16, 128), (35, 57, 9, 256), (4, 64, 10, 64),
+                                   (5, 64, 10, 200), (34, 24, 6, 80), (3, 64, 10, 4)])
 @pytest.mark.parametrize("variant", ["softmax", "contrast"])
 def test_uneven_members_every_d(GF, shape, variant):
     B, N, M, D = shape
