@@ -33,7 +33,7 @@ bool shape_ok(int B, int N, int M, int D) { return B >= 1 && N >= 1 && M >= 2 &&
 constexpr int kSplitMinB = 208, kSplitMaxB = 256;
 
 // The team kernel wants its workgroups co-resident.  It survives a busy device (waits bounded to milliseconds, then the
-// gated fall-back launch redoes the call), but a caller that KNOWS it shares the GPU -- overlapped collectives, several
+// workgroups of the same launch redo the call without teams), but a caller that KNOWS it shares the GPU -- overlapped collectives, several
 // processes -- asks for GE2E_IMPL_AUTO_NO_TEAM (the only switch: the GE2E_AUTO_NO_TEAM environment override of rounds 2-3
 // is gone, an implementation choice is an argument of the call).
 
@@ -331,7 +331,7 @@ int ge2e_sample_batch(const void* store, int store_is_f64, const long long* spk_
                                     (hipStream_t)stream);
 }
 
-// GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the gated fall-back launch does the work.
+// GE2E_IMPL_TEAM with its abort word raised before the launch: no team forms, the launch redoes the call with one workgroup per batch.
 int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, const float* w, const float* b,
                                 float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {

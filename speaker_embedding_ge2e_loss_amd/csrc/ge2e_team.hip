@@ -91,8 +91,10 @@ int team_fallback_grid(int B) {
     const int cus = team_cu_count();
     return B < cus ? B : cus;
 }
+// one slice per workgroup of the team grid (a redo is shared by team_fallback_grid(B) of them; a workgroup whose end-of-grid
+// wait ran out redoes the call alone in ITS slice)
 static size_t team_fb_bytes(int B, int N, int M, int D) {
-    const int g = team_fallback_grid(B);
+    const int g = team_grid(B) > team_fallback_grid(B) ? team_grid(B) : team_fallback_grid(B);
     return (size_t)g * fused_split_layout(N, M, D).stride * sizeof(float);
 }
 size_t team_workspace_bytes(int B, int N, int M, int D) {
@@ -106,7 +108,7 @@ size_t team_workspace_bytes(int B, int N, int M, int D) {
 // FWD: the forward-only instantiation of the metric shape (similarity + loss, dE == NULL known at compile time: no held /
 // fragment / partial-gradient registers, no gradient phases in the loop at all).
 template <int NCH, int MR, int RBT, bool CONTRAST, bool FWD = false>
-__global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L) {
+__global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L, FusedWs F) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
@@ -152,8 +154,16 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L)
     TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
     TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
     const TeamId id = team_form(ctl, SH);
-    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the gated launch takes over
+    if (id.team == -2) {    // a control block that cannot be trusted: no counters at all -- static redo, workgroup 0 leaves a clean block
+        team_redo<NCH>(p, L, F, smem_f, false);
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u);
+        return;
+    }
+    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the call is redone at the end of this launch
         __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the team part as a block of its own: workgroups without a team skip it and meet the others in team_finish below)
+    [&]() __attribute__((always_inline)) {
     if (id.team < 0) return;
     TeamKFlags* const fl = flags + id.team;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
@@ -912,6 +922,16 @@ _Pragma("unroll")                                                               
     }
     if (failed && tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     GE2E_PROF_FLUSH(20)
+    }();
+    // ---- end of the launch: the whole grid meets, the last workgroup hands the control block back clean, and if anything
+    //      went wrong on the way the SAME workgroups redo the call with the one-workgroup-per-batch body
+    {
+        int* const fsh = reinterpret_cast<int*>(smem_f) + 4;     // (LDS is free now: every wave of this workgroup is here)
+        if (team_finish(ctl, fsh, (int)(L.head_bytes / 16))) {
+            const bool solo = team_finish_solo(fsh);
+            team_redo<NCH>(p, L, F, smem_f, solo);
+        }
+    }
 #undef GE2E_PROF_SUB
 #undef GE2E_T2_LOAD_ROWS
 #undef GE2E_T2_LANE
@@ -937,80 +957,67 @@ hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hip
 }
 
 template <int NCH, int MR, int RBT, bool CONTRAST, bool FWD = false>
-static hipError_t launch_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
+static hipError_t launch_nch(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(ge2e_team_kernel<NCH, MR, RBT, CONTRAST, FWD>);
     static KernelLaunchState state;     // one per instantiation; per-device entries inside
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, (unsigned)L.lds_bytes, &nb);
     if (err != hipSuccess) return err;
-    // No zeroing launch: the control block is self-cleaning (ge2e_team.hpp) -- the previous call's gated launch left it
-    // clean, ge2e_workspace_init wrote a first clean one, and anything else makes this launch fall back and be cleaned
-    // up after.  (p.test_abort: diagnostics, a block with the abort word raised is written in front of the launch.)
+    // ONE launch per call: the control block is self-cleaning (ge2e_team.hpp) -- the previous call's last workgroup left it
+    // clean, ge2e_workspace_init wrote a first clean one, and anything else makes this launch redo itself without teams
+    // and leave a clean block.  (p.test_abort: diagnostics, a block with the abort word raised is written in front.)
     if (p.test_abort) {
         err = launch_team_head_init(p.ws, L.head_bytes, true, stream);
         if (err != hipSuccess) return err;
     }
     // Every workgroup must be resident (they wait for each other): grid <= resident capacity is what a cooperative
     // launch checks; the same check is made here and the kernel goes out as an ordinary launch.  Should the teams
-    // not form, or a bounded spin run out, the kernel raises the control block's abort word and the gated launch
-    // behind it redoes every batch with the one-workgroup-per-batch kernel.
+    // not form, or a bounded spin run out, the kernel raises the control block's abort word and its own workgroups
+    // redo every batch with the one-workgroup-per-batch body once the whole grid has met (team_finish).
     int grid = team_grid(p.B);
     if (p.grid_cap > 0 && p.grid_cap < grid)      // diagnostics: fewer teams, more batches through each (whole XCD rounds)
         grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;
     if (nb < 1 || grid > nb * team_cu_count()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST, FWD>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L);
+    hipLaunchKernelGGL((ge2e_team_kernel<NCH, MR, RBT, CONTRAST, FWD>), dim3(grid), dim3(512), L.lds_bytes, stream, p, L, F);
     return hipGetLastError();
 }
 template <int NCH, int MR>
-static hipError_t launch_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
+static hipError_t launch_variant(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream) {
     if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64 && p.D == 256) {   // the metric shape: compile-time N, M, D, trip counts
         if (p.dE == nullptr)    // ... and its forward-only form (evaluation: s4:61-110, s5:42-44)
-            return p.variant == 1 ? launch_nch<4, 10, 5, true, true>(p, L, stream) : launch_nch<4, 10, 5, false, true>(p, L, stream);
-        return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, stream) : launch_nch<4, 10, 5, false>(p, L, stream);
+            return p.variant == 1 ? launch_nch<4, 10, 5, true, true>(p, L, F, stream) : launch_nch<4, 10, 5, false, true>(p, L, F, stream);
+        return p.variant == 1 ? launch_nch<4, 10, 5, true>(p, L, F, stream) : launch_nch<4, 10, 5, false>(p, L, F, stream);
     }
-    return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, stream) : launch_nch<NCH, MR, 0, false>(p, L, stream);
+    return p.variant == 1 ? launch_nch<NCH, MR, 0, true>(p, L, F, stream) : launch_nch<NCH, MR, 0, false>(p, L, F, stream);
 }
 
 hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem p = p_in;
     TeamKWs L = team_layout(p.N, p.M, p.D);
+    const FusedWs F = fused_split_layout(p.N, p.M, p.D);
+    // the redo body's slices behind the teams' exchange areas; its LDS if that is larger than the team kernel's
+    L.fb_off = align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange((p.D + 63) / 64 * 64).stride, 256);
+    L.fb_wgs = team_fallback_grid(p.B);
+    if (fused_split_lds_bytes(p.D) > L.lds_bytes) L.lds_bytes = fused_split_lds_bytes(p.D);
     hipError_t err;
     if (p.dE == nullptr) {          // similarity + loss only: the pipelined forward kernel (ge2e_team_fwd.hip)
-        err = launch_team_fwd(p, L, stream);
+        err = launch_team_fwd(p, L, F, stream);
     } else if (p.M <= 10) {
         switch ((p.D + 63) / 64) {
-            case 1: err = launch_variant<1, 10>(p, L, stream); break;
-            case 2: err = launch_variant<2, 10>(p, L, stream); break;
-            case 3: err = launch_variant<3, 10>(p, L, stream); break;
-            default: err = launch_variant<4, 10>(p, L, stream); break;
+            case 1: err = launch_variant<1, 10>(p, L, F, stream); break;
+            case 2: err = launch_variant<2, 10>(p, L, F, stream); break;
+            case 3: err = launch_variant<3, 10>(p, L, F, stream); break;
+            default: err = launch_variant<4, 10>(p, L, F, stream); break;
         }
     } else {
         switch ((p.D + 63) / 64) {
-            case 1: err = launch_variant<1, 16>(p, L, stream); break;
-            case 2: err = launch_variant<2, 16>(p, L, stream); break;
-            case 3: err = launch_variant<3, 16>(p, L, stream); break;
-            default: err = launch_variant<4, 16>(p, L, stream); break;
+            case 1: err = launch_variant<1, 16>(p, L, F, stream); break;
+            case 2: err = launch_variant<2, 16>(p, L, F, stream); break;
+            case 3: err = launch_variant<3, 16>(p, L, F, stream); break;
+            default: err = launch_variant<4, 16>(p, L, F, stream); break;
         }
     }
-    if (err != hipSuccess) return err;
-    // gated fall-back: runs only if the team kernel raised its abort word (workgroups exit at once otherwise)
-    Problem f = p_in;
-    const TeamCtl* ctl = reinterpret_cast<const TeamCtl*>(p_in.ws);
-    f.gate = &ctl->abort_;
-    f.cleanup_head = reinterpret_cast<unsigned*>(p_in.ws);     // its last workgroup hands the control block back clean
-    f.cleanup_n16 = (int)(L.head_bytes / 16);
-    f.grid_cap = team_fallback_grid(p.B);
-    f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p_in.ws) +
-                                    align_up(L.head_bytes + (size_t)(team_grid(p.B) / TEAM) * team_exchange((p.D + 63) / 64 * 64).stride, 256));
-    err = launch_fused_split(f, stream);
-    if (err != hipSuccess) {
-        // The team kernel is queued and NOTHING behind it will clean the control block (tickets, arrival count, hand-off
-        // counters, magic still set): the next call would form teams from stale tickets.  Rewrite a clean block behind it
-        // (stream order) and report the launch error.
-        launch_team_head_init(p_in.ws, L.head_bytes, false, stream);
-        return err;
-    }
-    return hipSuccess;
+    return err;
 }
 
 }  // namespace ge2e

@@ -30,14 +30,18 @@ constexpr int MAX_XCD = 8;
 constexpr unsigned long long TEAM_FORM_TICKS = 200000ull;      // 2 ms: every workgroup of the grid has started
 constexpr unsigned long long TEAM_HANDOFF_TICKS = 400000ull;   // 4 ms: a hand-off inside a running team
 
-// Control block at the head of the workspace.  SELF-CLEANING (round 4): a call leaves it the way it found it -- all zeros
-// plus the magic word -- so the steady state has no zeroing launch in front of the team kernel:
-//   * the LAST workgroup of the gated fall-back launch behind the team kernel (every call has one) re-zeroes the block
-//     and sets `magic` again (`done` counts its workgroups; by then every one of them has read the gate);
-//   * a block that does not carry the magic -- a fresh allocation, memory another implementation has written over -- makes
-//     every workgroup raise the abort word instead of forming teams: the fall-back computes that call and its clean-up
-//     leaves a valid block behind.  ge2e_workspace_init() (include/ge2e_hip.h) writes a valid block explicitly, so that
-//     a new workspace's first call already runs the team kernel; the Python side does that in alloc_workspace.
+// Control block at the head of the workspace.  SELF-CLEANING: a call leaves it the way it found it -- all zeros plus the
+// magic word -- and ONE launch does everything (round 5; rounds 2-4 queued a gated one-workgroup-per-batch launch behind
+// every team launch, which redid the call when the abort word was up and cleaned the block either way):
+//   * every workgroup of the team launch ends in team_finish(): it counts itself in `done`, waits until the whole grid has
+//     (all workgroups are resident -- the launch condition), reads the abort word, counts itself in `seen`; the workgroup
+//     that completes `seen` rewrites the block (nobody reads it any more).  With the abort word up -- no team formed, a
+//     hand-off timed out -- ALL workgroups are still there and redo the call with the one-workgroup-per-batch body
+//     (ge2e_fused_split_body.hpp), batches wg, wg + n, ...: never NaN, never stale outputs, no second launch;
+//   * a block that does not carry the magic -- a fresh allocation, memory another implementation has written over -- holds
+//     no counter that can be trusted: no teams, no end-of-grid wait; the workgroups redo the call with the same static
+//     split and workgroup 0 writes a valid block when it is done.  ge2e_workspace_init() (include/ge2e_hip.h) writes a valid
+//     block explicitly, so that a new workspace's first call already runs the team kernel; alloc_workspace does that.
 // (Zeroed by a kernel, not a memset node: captured in a HIP graph beside torch's fill nodes, a memset node replayed with
 // another node's pattern.)  Each word that is polled or bumped sits on its own 128-byte line.
 constexpr unsigned TEAM_MAGIC = 0x6E2E7EA3u;
@@ -46,31 +50,24 @@ struct TeamCtl {
     unsigned abort_;    unsigned pad1[31];
     unsigned nct;       unsigned pad2[31];              // complete teams (written by workgroup 0, diagnostic)
     unsigned xcd_count[MAX_XCD][32];                    // one line per XCD
-    unsigned done;      unsigned pad3[31];              // workgroups of the gated fall-back launch that have finished
+    unsigned done;      unsigned pad3[31];              // workgroups that have finished their batches (team_finish)
     unsigned magic;     unsigned pad4[31];              // TEAM_MAGIC <=> the rest of the block (and the team flags) is zero
     unsigned fallbacks; unsigned pad5[31];              // diagnostic, survives the clean-up: calls on this workspace whose abort
                                                         // word was up (no team formed, a hand-off timed out, unclean block)
+    unsigned seen;      unsigned pad6[31];              // workgroups that have read the abort word at the end (team_finish)
 };
+constexpr unsigned long long TEAM_FINISH_TICKS = 5000000ull;    // 50 ms: the whole grid has finished (every inner wait is bounded
+                                                                // by 4 ms and gives up as soon as the abort word rises)
 // bytes of the control block + 64 per-team flag records (shape-independent; TeamKFlags = 3 lines, TeamFlags = 2)
 constexpr size_t team_head_bytes() { return (sizeof(TeamCtl) + 64 * 3 * 128 + 255) / 256 * 256; }
 // zero `bytes` at `head` (a multiple of 16) and set the magic (and, for diagnostics, the abort word): one small launch
 hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hipStream_t stream);
-// Clean-up half of the protocol, called by ALL threads of EVERY workgroup of the gated launch right before they leave (also
-// when the gate was down): the last workgroup restores the clean block.
-__device__ __forceinline__ void team_head_cleanup(unsigned* head, int n16) {
-    if (head == nullptr || threadIdx.x >= 64) return;
-    TeamCtl* ctl = reinterpret_cast<TeamCtl*>(head);
-    int last = 0;
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last) return;
+// a clean block (zeros + magic + the surviving fall-back count) over `n16` 16-byte pieces; called by one wave (64 threads)
+__device__ __forceinline__ void team_head_rewrite(unsigned* head, int n16, unsigned fallbacks) {
     constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
-    // (the team kernel and every other workgroup of this launch are done with the block: plain accesses)
-    const bool was_clean = ctl->magic == TEAM_MAGIC;
-    const unsigned fb = (was_clean ? ctl->fallbacks : 0u) + (ctl->abort_ != 0u ? 1u : 0u);
     uint4* h16 = reinterpret_cast<uint4*>(head);
-    for (int i = threadIdx.x; i < n16; i += 64)
-        h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fb : 0u), 0u, 0u, 0u);
+    for (int i = threadIdx.x & 63; i < n16; i += 64)
+        h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fallbacks : 0u), 0u, 0u, 0u);
 }
 struct TeamFlags {                                      // per team
     unsigned c1;        unsigned pad0[31];              // hand-off 1 (unit centroids published)
@@ -78,7 +75,7 @@ struct TeamFlags {                                      // per team
 };
 
 struct TeamId {
-    int team;      // index among the complete teams, -1 = not in one
+    int team;      // index among the complete teams, -1 = not in one, -2 = the control block cannot be trusted (no counters)
     int member;    // 0..7
     int nct;       // number of complete teams
 };
@@ -114,12 +111,9 @@ __device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, T
 // Called by all threads of the workgroup; `sh` is 4 ints of LDS.  Contains workgroup barriers.
 __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
     if (threadIdx.x == 0 && ld_poll(&ctl->magic) != TEAM_MAGIC) {
-        // not a clean control block (fresh or overwritten memory): no counter in it can be trusted.  Everybody raises the
-        // abort word (the gated launch tests != 0) and leaves; the fall-back computes the call and its last workgroup
-        // writes a clean block.
-        __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the clean-up's own counter starts from zero
-        sh[0] = -1; sh[1] = 0; sh[2] = 0;
+        // not a clean control block (fresh or overwritten memory): no counter in it can be trusted, so no teams and no
+        // end-of-grid protocol either -- the caller redoes the call with a static split and workgroup 0 writes a clean block
+        sh[0] = -2; sh[1] = 0; sh[2] = 0;
     } else if (threadIdx.x == 0 && ld_poll(&ctl->abort_)) {   // launch already marked as failed (diagnostics): nobody forms a team
         sh[0] = -1; sh[1] = 0; sh[2] = 0;
     } else if (threadIdx.x == 0) {
@@ -143,6 +137,53 @@ __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
     id.team = sh[0]; id.member = sh[1]; id.nct = sh[2];
     return id;
 }
+
+// one lane: wait until *p >= target whatever the abort word says (the end-of-grid wait)
+__device__ __forceinline__ bool spin_until_all(const unsigned* p, unsigned target, unsigned long long ticks) {
+    if ((int)(ld_poll(p) - target) >= 0) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned it = 0;; ++it) {
+        if ((int)(ld_poll(p) - target) >= 0) return true;
+        if ((it & 63) == 63 && __builtin_amdgcn_s_memrealtime() - t0 > ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// End of a team launch on a TRUSTED control block, called by all threads of every workgroup (also the ones without a team or
+// without a batch): true (uniformly over the whole grid) when the call has to be redone by the one-workgroup-per-batch body.
+// `sh`: 2 ints of LDS.  `n16`: size of the control block + flags in 16-byte pieces.
+__device__ __forceinline__ bool team_finish(TeamCtl* ctl, int* sh, int n16) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        add_agent(&ctl->done, 1u);
+        unsigned redo = 0u, solo = 0u;
+        if (spin_until_all(&ctl->done, gridDim.x, TEAM_FINISH_TICKS)) {
+            redo = ld_poll(&ctl->abort_) != 0u ? 1u : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the abort word has been READ before this workgroup counts as "seen"
+            const unsigned s = add_agent(&ctl->seen, 1u);
+            sh[1] = s == gridDim.x - 1 ? 1 : 0;                    // the last reader: the block is nobody's any more
+        } else {
+            // a workgroup of this grid has not finished within 50 ms: nothing about the block holds any more.  Take the magic
+            // away (the next call redoes itself without counters and writes a fresh block) and redo this call ALONE.
+            __hip_atomic_store(&ctl->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            redo = 1u; solo = 1u;
+            sh[1] = 0;
+        }
+        sh[0] = (int)(redo | (solo << 1));
+    }
+    __syncthreads();
+    const int r = sh[0];
+    if (sh[1] && threadIdx.x < 64) {
+        const bool was = ctl->abort_ != 0u;
+        team_head_rewrite(reinterpret_cast<unsigned*>(ctl), n16, ctl->fallbacks + (was ? 1u : 0u));
+    }
+    __syncthreads();
+    return r != 0;
+}
+// ... and whether that redo is this workgroup's alone (the end-of-grid wait ran out): every batch, not a share
+__device__ __forceinline__ bool team_finish_solo(const int* sh) { return (sh[0] & 2) != 0; }
 
 // Producer side of a hand-off: call from ALL threads after the payload stores were issued.
 __device__ __forceinline__ void team_signal(unsigned* counter) {

@@ -4,6 +4,8 @@
 #include "ge2e_common.hpp"
 #include "ge2e_split_gemm.hpp"
 #include "ge2e_team.hpp"
+#include "ge2e_team_kernel.hpp"
+#include "ge2e_fused_split_body.hpp"
 
 namespace ge2e {
 
@@ -167,6 +169,23 @@ __device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned targ
     if (threadIdx.x == 0) *w = spin_until(counter, target, ctl) ? 1 : 0;
     __syncthreads();
     return *w != 0;
+}
+
+// The call is redone by the one-workgroup-per-batch body inside this launch (team_finish said so, or the control block could
+// not be trusted): workgroup b takes the batches b, b + n, ... in workspace slice b -- or, `solo`, every batch by itself (the
+// end-of-grid wait ran out: what the others do is unknown; same results, written twice at worst).
+template <int NCH>
+__device__ __forceinline__ void team_redo(const Problem& p, const TeamKWs& L, const FusedWs& F, float* smem_f, bool solo) {
+    Problem f = p;
+    f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p.ws) + L.fb_off);
+    __syncthreads();
+    const int n = min((int)gridDim.x, L.fb_wgs);
+    if (solo) {
+        f.ws += (size_t)blockIdx.x * F.stride;       // this workgroup's own slice, every batch
+        fsplit::body<NCH>(f, F, smem_f, 0, 1);
+    } else if ((int)blockIdx.x < n) {
+        fsplit::body<NCH>(f, F, smem_f, (int)blockIdx.x, n);
+    }
 }
 
 }  // namespace

@@ -41,7 +41,7 @@ size_t team_fwd_lds_bytes(int rt, int D) {
 }
 
 template <int NCH, int MR, int RBT, bool CONTRAST>
-__global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKWs L) {
+__global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKWs L, FusedWs F) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int D = 64 * NCH;
     constexpr int P = D;                  // image pitch: no padding, chunks swizzled by row (et_off)
@@ -72,8 +72,16 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
     TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
     const TeamId id = team_form(ctl, SH);
-    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the gated launch takes over
+    if (id.team == -2) {    // a control block that cannot be trusted: no counters at all -- static redo, workgroup 0 leaves a clean block
+        team_redo<NCH>(p, L, F, smem_f, false);
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u);
+        return;
+    }
+    if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the call is redone at the end of this launch
         __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the team part as a block of its own: workgroups without a team skip it and meet the others in team_finish below)
+    [&]() __attribute__((always_inline)) {
     if (id.team < 0) return;
     TeamKFlags* const fl = flags + id.team;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(
@@ -582,16 +590,27 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     }
     if (failed && (threadIdx.x & 63) == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     GE2E_PROF_FLUSH(20)
+    }();
+    // ---- end of the launch: the whole grid meets, the last workgroup hands the control block back clean, and if anything
+    //      went wrong on the way the SAME workgroups redo the call with the one-workgroup-per-batch body (ge2e_team.hpp)
+    {
+        int* const fsh = reinterpret_cast<int*>(smem_f) + 4;
+        if (team_finish(ctl, fsh, (int)(L.head_bytes / 16))) {
+            const bool solo = team_finish_solo(fsh);
+            team_redo<NCH>(p, L, F, smem_f, solo);
+        }
+    }
 #undef GE2E_TF_LOAD_ROWS
 #undef GE2E_TF_LANE
 #undef GE2E_TF_CONSTS
 }
 
 template <int NCH, int MR, int RBT, bool CONTRAST>
-static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
+static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>);
     static KernelLaunchState state;
-    const unsigned lds = (unsigned)team_fwd_lds_bytes(L.rt, 64 * NCH);       // (NCH = ceil(D / 64): padded columns)
+    unsigned lds = (unsigned)team_fwd_lds_bytes(L.rt, 64 * NCH);             // (NCH = ceil(D / 64): padded columns)
+    if (fused_split_lds_bytes(p.D) > lds) lds = (unsigned)fused_split_lds_bytes(p.D);   // ... or the redo body's
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, lds, &nb);
     if (err != hipSuccess) return err;
@@ -603,31 +622,31 @@ static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, hipStream_t stream) {
     if (p.grid_cap > 0 && p.grid_cap < grid)
         grid = p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) > 0 ? p.grid_cap / (MAX_XCD * TEAM) * (MAX_XCD * TEAM) : MAX_XCD * TEAM;
     if (nb < 1 || grid > nb * device_cu_count()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), lds, stream, p, L);
+    hipLaunchKernelGGL((ge2e_team_fwd_kernel<NCH, MR, RBT, CONTRAST>), dim3(grid), dim3(512), lds, stream, p, L, F);
     return hipGetLastError();
 }
 template <int NCH, int MR>
-static hipError_t launch_fwd_variant(Problem& p, TeamKWs& L, hipStream_t stream) {
+static hipError_t launch_fwd_variant(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream) {
     if (NCH == 4 && MR == 10 && L.rt == 80 && p.M == 10 && p.N == 64 && p.D == 256)     // the metric shape: compile-time N, M, D
-        return p.variant == 1 ? launch_fwd_nch<4, 10, 5, true>(p, L, stream) : launch_fwd_nch<4, 10, 5, false>(p, L, stream);
-    return p.variant == 1 ? launch_fwd_nch<NCH, MR, 0, true>(p, L, stream) : launch_fwd_nch<NCH, MR, 0, false>(p, L, stream);
+        return p.variant == 1 ? launch_fwd_nch<4, 10, 5, true>(p, L, F, stream) : launch_fwd_nch<4, 10, 5, false>(p, L, F, stream);
+    return p.variant == 1 ? launch_fwd_nch<NCH, MR, 0, true>(p, L, F, stream) : launch_fwd_nch<NCH, MR, 0, false>(p, L, F, stream);
 }
 
-// the team launch of a forward-only call (p.dE == NULL); the caller (launch_team) queues the gated fall-back behind it
-hipError_t launch_team_fwd(Problem& p, TeamKWs& L, hipStream_t stream) {
+// the team launch of a forward-only call (p.dE == NULL)
+hipError_t launch_team_fwd(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream) {
     if (p.M <= 10) {
         switch ((p.D + 63) / 64) {
-            case 1: return launch_fwd_variant<1, 10>(p, L, stream);
-            case 2: return launch_fwd_variant<2, 10>(p, L, stream);
-            case 3: return launch_fwd_variant<3, 10>(p, L, stream);
-            default: return launch_fwd_variant<4, 10>(p, L, stream);
+            case 1: return launch_fwd_variant<1, 10>(p, L, F, stream);
+            case 2: return launch_fwd_variant<2, 10>(p, L, F, stream);
+            case 3: return launch_fwd_variant<3, 10>(p, L, F, stream);
+            default: return launch_fwd_variant<4, 10>(p, L, F, stream);
         }
     }
     switch ((p.D + 63) / 64) {
-        case 1: return launch_fwd_variant<1, 16>(p, L, stream);
-        case 2: return launch_fwd_variant<2, 16>(p, L, stream);
-        case 3: return launch_fwd_variant<3, 16>(p, L, stream);
-        default: return launch_fwd_variant<4, 16>(p, L, stream);
+        case 1: return launch_fwd_variant<1, 16>(p, L, F, stream);
+        case 2: return launch_fwd_variant<2, 16>(p, L, F, stream);
+        case 3: return launch_fwd_variant<3, 16>(p, L, F, stream);
+        default: return launch_fwd_variant<4, 16>(p, L, F, stream);
     }
 }
 

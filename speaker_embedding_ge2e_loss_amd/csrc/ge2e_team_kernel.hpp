@@ -3,6 +3,7 @@
 #pragma once
 #include "ge2e_common.hpp"
 #include "ge2e_team.hpp"   // formation + hand-off building blocks
+#include "ge2e_fused.hpp"  // FusedWs: the layout of the body that redoes a call without teams
 
 namespace ge2e {
 
@@ -43,6 +44,10 @@ struct TeamKWs {
     unsigned head_bytes;   // TeamCtl + TeamKFlags[64]
     unsigned xb_bytes, g_bytes;   // LDS regions that are shared by two uses (see the kernel)
     size_t lds_bytes;
+    // the in-launch redo (team_finish, ge2e_team.hpp): byte offset of the one-workgroup-per-batch body's workspace slices behind
+    // the exchange areas (one slice per workgroup of the team grid), and how many workgroups share the batches of a redo
+    size_t fb_off;
+    int fb_wgs;
 };
 
 int team_fallback_grid(int B);           // workgroups of the gated fall-back launch: one per batch up to one per CU
@@ -53,7 +58,8 @@ int team_grid(int B);
 size_t team_workspace_bytes(int B, int N, int M, int D);
 hipError_t launch_team(const Problem& p, hipStream_t stream);
 // forward-only calls (p.dE == NULL): the team launch alone, ge2e_team_fwd.hip; launch_team queues the gated fall-back behind it
-hipError_t launch_team_fwd(Problem& p, TeamKWs& L, hipStream_t stream);
+hipError_t launch_team_fwd(Problem& p, TeamKWs& L, const FusedWs& F, hipStream_t stream);
+// LDS of a team launch: the team kernel's own, or the redo body's if that is larger
 size_t team_fwd_lds_bytes(int rt, int D);
 
 }  // namespace ge2e
