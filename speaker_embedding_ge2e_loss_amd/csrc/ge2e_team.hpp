@@ -150,40 +150,63 @@ __device__ __forceinline__ bool spin_until_all(const unsigned* p, unsigned targe
 }
 
 // End of a team launch on a TRUSTED control block, called by all threads of every workgroup (also the ones without a team or
-// without a batch): true (uniformly over the whole grid) when the call has to be redone by the one-workgroup-per-batch body.
-// `sh`: 2 ints of LDS.  `n16`: size of the control block + flags in 16-byte pieces.
-__device__ __forceinline__ bool team_finish(TeamCtl* ctl, int* sh, int n16) {
+// without a batch).  The common case costs one load and one atomic and waits for nobody: a workgroup that finds the abort
+// word down counts itself in `done` and leaves; the one that completes the count rewrites the block (everybody else has
+// left).  A workgroup that finds the abort word UP takes a rank in `seen`, counts itself in `done` as well and STAYS until
+// the count is complete; the last finisher joins them if the word is up by then (it may have risen late).  Those that stayed
+// redo the call with the one-workgroup-per-batch body, batches rank, rank + n, ...: all of the grid when no team could
+// form (the word is up before anybody finishes), at least the team whose hand-off ran out otherwise.  Returns the number of
+// workgroups in the redo (0: none, leave) and this workgroup's rank; the caller ends with team_redo_done().
+// `sh`: 4 ints of LDS.  `n16`: size of the control block + flags in 16-byte pieces.
+struct TeamRedo { int n, rank; };
+// `known_up`: this workgroup knows the word is (being) raised -- no team formed anywhere, or its own hand-off ran out.
+__device__ __forceinline__ TeamRedo team_finish(TeamCtl* ctl, int* sh, int n16, bool known_up) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        add_agent(&ctl->done, 1u);
-        unsigned redo = 0u, solo = 0u;
-        if (spin_until_all(&ctl->done, gridDim.x, TEAM_FINISH_TICKS)) {
-            redo = ld_poll(&ctl->abort_) != 0u ? 1u : 0u;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the abort word has been READ before this workgroup counts as "seen"
-            const unsigned s = add_agent(&ctl->seen, 1u);
-            sh[1] = s == gridDim.x - 1 ? 1 : 0;                    // the last reader: the block is nobody's any more
-        } else {
-            // a workgroup of this grid has not finished within 50 ms: nothing about the block holds any more.  Take the magic
-            // away (the next call redoes itself without counters and writes a fresh block) and redo this call ALONE.
-            __hip_atomic_store(&ctl->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            redo = 1u; solo = 1u;
-            sh[1] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this workgroup's results are out
+        int n = 0, rank = 0, clean = 0;
+        unsigned up = ld_poll(&ctl->abort_) | (known_up ? 1u : 0u);
+        if (up) rank = (int)add_agent(&ctl->seen, 1u);              // (returned before `done` moves: the two are ordered)
+        const bool last = add_agent(&ctl->done, 1u) == gridDim.x - 1;
+        if (!up && last) {
+            up = ld_poll(&ctl->abort_);                             // final: everybody else has finished
+            if (up) rank = (int)add_agent(&ctl->seen, 1u);
+            else clean = 1;
         }
-        sh[0] = (int)(redo | (solo << 1));
+        if (up) {
+            if (last || spin_until_all(&ctl->done, gridDim.x, TEAM_FINISH_TICKS)) {
+                n = (int)ld_poll(&ctl->seen);                       // every stayer took its rank before it counted in `done`
+            } else {
+                // a workgroup of this grid has not finished within 50 ms: nothing about the block holds any more.  Take the
+                // magic away (the next call redoes itself without counters and writes a fresh block) and redo ALONE.
+                __hip_atomic_store(&ctl->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n = -1;
+            }
+        }
+        sh[0] = n; sh[1] = rank; sh[2] = clean;
     }
     __syncthreads();
-    const int r = sh[0];
-    if (sh[1] && threadIdx.x < 64) {
-        const bool was = ctl->abort_ != 0u;
-        team_head_rewrite(reinterpret_cast<unsigned*>(ctl), n16, ctl->fallbacks + (was ? 1u : 0u));
+    TeamRedo r{sh[0], sh[1]};
+    if (sh[2]) {                                                    // nobody else is left: a clean block for the next call
+        const unsigned fb = ctl->fallbacks;
+        constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
+        uint4* h16 = reinterpret_cast<uint4*>(ctl);
+        for (int i = threadIdx.x; i < n16; i += blockDim.x)
+            h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fb : 0u), 0u, 0u, 0u);
     }
-    __syncthreads();
-    return r != 0;
+    return r;
 }
-// ... and whether that redo is this workgroup's alone (the end-of-grid wait ran out): every batch, not a share
-__device__ __forceinline__ bool team_finish_solo(const int* sh) { return (sh[0] & 2) != 0; }
+// ... after the redo: the last of its workgroups rewrites the block (the `nct` word counts them; it is diagnostic otherwise)
+__device__ __forceinline__ void team_redo_done(TeamCtl* ctl, int* sh, int n16, int n) {
+    __syncthreads();
+    if (n < 0) return;                                              // redone alone, the block is marked untrusted
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh[0] = add_agent(&ctl->xcd_count[0][1], 1u) == (unsigned)(n - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (sh[0] && threadIdx.x < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), n16, ctl->fallbacks + 1u);
+}
 
 // Producer side of a hand-off: call from ALL threads after the payload stores were issued.
 __device__ __forceinline__ void team_signal(unsigned* counter) {

@@ -172,19 +172,20 @@ __device__ __forceinline__ bool team_wait(const unsigned* counter, unsigned targ
 }
 
 // The call is redone by the one-workgroup-per-batch body inside this launch (team_finish said so, or the control block could
-// not be trusted): workgroup b takes the batches b, b + n, ... in workspace slice b -- or, `solo`, every batch by itself (the
-// end-of-grid wait ran out: what the others do is unknown; same results, written twice at worst).
+// not be trusted): workgroup `rank` of `n` takes the batches rank, rank + n, ... in workspace slice `rank` -- or, n < 0,
+// every batch by itself in the slice of its block index (the end-of-grid wait ran out: what the others do is unknown; same
+// results, written twice at worst).
 template <int NCH>
-__device__ __forceinline__ void team_redo(const Problem& p, const TeamKWs& L, const FusedWs& F, float* smem_f, bool solo) {
+__device__ __forceinline__ void team_redo(const Problem& p, const TeamKWs& L, const FusedWs& F, float* smem_f, int n, int rank) {
     Problem f = p;
     f.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(p.ws) + L.fb_off);
     __syncthreads();
-    const int n = min((int)gridDim.x, L.fb_wgs);
-    if (solo) {
-        f.ws += (size_t)blockIdx.x * F.stride;       // this workgroup's own slice, every batch
+    if (n < 0) {
+        f.ws += (size_t)blockIdx.x * F.stride;
         fsplit::body<NCH>(f, F, smem_f, 0, 1);
-    } else if ((int)blockIdx.x < n) {
-        fsplit::body<NCH>(f, F, smem_f, (int)blockIdx.x, n);
+    } else {
+        if (n > L.fb_wgs) n = L.fb_wgs;              // (no more workgroups than batches)
+        if (rank < n) fsplit::body<NCH>(f, F, smem_f, rank, n);
     }
 }
 

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
     const TeamId id = team_form(ctl, SH);
     if (id.team == -2) {    // a control block that cannot be trusted: no counters at all -- static redo, workgroup 0 leaves a clean block
-        team_redo<NCH>(p, L, F, smem_f, false);
+        team_redo<NCH>(p, L, F, smem_f, (int)gridDim.x, (int)blockIdx.x);
         __syncthreads();
         if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u);
         return;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the call is redone at the end of this launch
         __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (the team part as a block of its own: workgroups without a team skip it and meet the others in team_finish below)
+    bool gave_up = id.nct == 0;     // this workgroup knows the call will be redone (no team anywhere; below: its own hand-off ran out)
     [&]() __attribute__((always_inline)) {
     if (id.team < 0) return;
     TeamKFlags* const fl = flags + id.team;
@@ -589,15 +590,17 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
         }
     }
     if (failed && (threadIdx.x & 63) == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gave_up = gave_up || failed;
     GE2E_PROF_FLUSH(20)
     }();
-    // ---- end of the launch: the whole grid meets, the last workgroup hands the control block back clean, and if anything
-    //      went wrong on the way the SAME workgroups redo the call with the one-workgroup-per-batch body (ge2e_team.hpp)
+    // ---- end of the launch (team_finish, ge2e_team.hpp): one load and one atomic in the common case, the last workgroup hands
+    //      the control block back clean; with the abort word up the workgroups that are still there redo the call
     {
         int* const fsh = reinterpret_cast<int*>(smem_f) + 4;
-        if (team_finish(ctl, fsh, (int)(L.head_bytes / 16))) {
-            const bool solo = team_finish_solo(fsh);
-            team_redo<NCH>(p, L, F, smem_f, solo);
+        const TeamRedo rd = team_finish(ctl, fsh, (int)(L.head_bytes / 16), gave_up);
+        if (rd.n != 0) {
+            team_redo<NCH>(p, L, F, smem_f, rd.n, rd.rank);
+            team_redo_done(ctl, fsh, (int)(L.head_bytes / 16), rd.n);
         }
     }
 #undef GE2E_TF_LOAD_ROWS
