@@ -51,9 +51,10 @@ extern "C" {
                                    v_mfma_f32_32x32x16_f16, fp32 accumulate      */
 #define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
 #define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, the member's rows resident in LDS: E is
-                                   read once.  Falls back to FUSED_SPLIT inside the same call (a gated second
-                                   launch) if the teams cannot form or a hand-off times out (see
-                                   GE2E_IMPL_AUTO_NO_TEAM)                                                     */
+                                   read once.  ONE launch per call: if the teams cannot form or a hand-off times
+                                   out, the same workgroups redo the call with FUSED_SPLIT's one-workgroup-per-batch
+                                   body before the launch ends (see GE2E_IMPL_AUTO_NO_TEAM).  D: any multiple of 4
+                                   up to 256 (padded to the next multiple of 64 inside the kernel)               */
 
 #define GE2E_IMPL_WAVE 6        /* one WAVE per batch, the batch in registers, exact fp32, no workspace: the reference's
                                    own shapes (up to 64 rows: N <= 3..12 depending on M in {2,3,4,5,6,8,10,16},
@@ -61,7 +62,7 @@ extern "C" {
 #define GE2E_IMPL_AUTO_NO_TEAM 7 /* AUTO without GE2E_IMPL_TEAM: for callers that KNOW other streams or processes keep
                                    CUs busy while the loss runs (overlapped collectives, a shared GPU).  The team kernel
                                    wants its workgroups co-resident; it survives a busy device (waits bounded to a few
-                                   milliseconds, then the fall-back launch), but not choosing it saves those waits.  */
+                                   milliseconds, then the in-launch redo), but not choosing it saves those waits.  */
 
 #define GE2E_OK 0
 #define GE2E_ERR_NULL (-1)      /* a required pointer is NULL                    */
@@ -85,8 +86,8 @@ size_t ge2e_workspace_bytes(int B, int N, int M, int D, int variant, int impl);
 /* OPTIONAL, once per workspace allocation (enqueue-only, one 2-us launch): writes the clean control block GE2E_IMPL_TEAM
  * expects at the head of its workspace.  The block is self-cleaning -- every call hands it back the way it found it, so
  * the steady state has no zeroing launch in front of the kernel -- and a workspace that was NOT initialised (or that another
- * implementation has used in between) is still safe: the first call on it is computed by the in-call fall-back launch,
- * which leaves a clean block behind.  Calling this just makes the first call already run the team kernel.  Workspaces
+ * implementation has used in between) is still safe: the first call on it is computed without teams (one workgroup
+ * per batch, inside the same launch), which leaves a clean block behind.  Calling this just makes the first call already run the team kernel.  Workspaces
  * smaller than the block (26 KB, the first bytes of every loss workspace whichever implementation runs) are left alone.  (The reference has no counterpart: s3's module allocates nothing.) */
 int ge2e_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
@@ -238,7 +239,7 @@ int ge2e_selftest_team(void* ws, size_t ws_bytes, int grid, int rounds, int payl
                        void* stream);
 
 /* ge2e_loss_fwd_bwd with impl = GE2E_IMPL_TEAM and the team kernel's abort word raised before the launch: exercises the
- * in-call fall-back (the gated one-workgroup-per-batch launch) deterministically.  Same arguments and results. */
+ * in-launch redo (the same workgroups, one per batch) deterministically.  Same arguments and results. */
 int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, const float* w, const float* b,
                                 float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);

@@ -97,8 +97,9 @@ def test_small_d_full_members(GF, shape, impl):
 
 
 def test_fallback_when_no_team_forms(GF):
-    """The team launch with its abort word raised: every workgroup leaves at once, the gated fall-back launch behind it
-    (same call, same stream) produces the results -- finite and correct, never NaN or stale memory."""
+    """The team launch with its abort word raised: no team forms, every workgroup finds the word up at the end of the launch,
+    stays, and together they redo the call with the one-workgroup-per-batch body (same launch) -- finite and correct, never
+    NaN or stale memory."""
     from speaker_embedding_ge2e_loss_amd import _lib
     lib = _lib.load()
     for (B, N, M, D) in ((1, 64, 10, 256), (70, 64, 10, 256), (9, 23, 7, 128)):
@@ -281,8 +282,8 @@ def test_thousand_batches_through_one_team(GF, shape, per_team):
 
 
 def test_control_block_cleans_itself(GF):
-    """Round 4: no zeroing launch in front of the team kernel.  A call leaves the control block clean (its gated launch's
-    last workgroup rewrites it), a workspace that was never initialised -- or that another implementation has written
+    """No zeroing launch in front of the team kernel and none behind it.  A call leaves the control block clean (the last
+    workgroup of the launch rewrites it), a workspace that was never initialised -- or that another implementation has written
     over -- makes the call fall back ONCE and come out clean, and `workspace_fallback_count` says which happened."""
     dev = torch.device("cuda:0")
     B, N, M, D = 5, 64, 10, 256

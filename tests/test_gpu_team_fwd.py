@@ -73,7 +73,8 @@ def test_metric_shape_kinds_and_no_wb(GF, variant, kind):
     o1 = run_fwd(GF, E, 10.0, -5.0, variant, want_wb=True)
     o0 = run_fwd(GF, E, 10.0, -5.0, variant, want_wb=False)
     check_fwd(o1, ref, f"{kind} {variant}")
-    assert np.array_equal(o0["loss"], o1["loss"]) and np.array_equal(o0["per"], o1["per"]) and o0["dw"] is None
+    # (without dw / db the softmax launch takes the fast form of S: another order of the same sums -- last-bit agreement)
+    assert np.allclose(o0["loss"], o1["loss"], rtol=1e-5) and np.allclose(o0["per"], o1["per"], rtol=5e-5, atol=2e-6) and o0["dw"] is None
 
 
 @pytest.mark.parametrize("wb", [(-3.0, 0.5), (0.0, 1.0), (60.0, -5.0), (1.0, 0.0)])
@@ -106,7 +107,7 @@ def test_equals_the_training_launch_and_is_bitwise_repeatable(GF):
 
 
 def test_workspace_is_left_clean_for_the_next_call(GF):
-    """The forward kernel ends with two extra signals on the team counters; the gated launch behind it hands the control
+    """The forward kernel ends with two extra signals on the team counters; its last workgroup hands the control
     block back zeroed: a training launch and another forward launch on the SAME workspace stay correct, no fall-back."""
     B, N, M, D = 70, 64, 10, 256
     dev = torch.device("cuda:0")

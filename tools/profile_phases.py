@@ -41,9 +41,10 @@ PHASES = {
               "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: slice-1 reads + 24 MFMAs issued", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: pieces + slice-0 reads + 24 MFMAs issued",
               "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: slice-1 reads + 24 MFMAs issued", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: pieces + slice-0 reads + 24 MFMAs issued"],
     # the pipelined forward-only team kernel (csrc/ge2e_team_fwd.hip)
-    "team_fwd": ["A1(cur) speaker sum -> centroid published", "X(prev) contraction -> XB", "drain (vmcnt 0)", "barrier 1 + signal",
-                 "A2(cur) rows -> images; RA <- RB; rows of n + 2 requested", "S(prev) softmax, loss", "poll c1(cur) + barrier 2",
-                 "requests: centroid fragments; member scalars"],
+    "team_fwd": ["poll c1(prev); A1(cur) speaker sum -> centroid published (prev's fragments requested underneath)",
+                 "A2(cur) compute half: norms, split halves in registers", "drain (vmcnt 0)", "barrier A + signal",
+                 "combine(prev - 1) [waves 4-7]; next rows requested; X(prev) contraction", "barrier B",
+                 "A2(cur) image writes; S(prev) [fast form: waves 0-3]", "-"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
@@ -55,6 +56,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batches", type=int, default=1024)
     ap.add_argument("--forward-only", action="store_true", help="dE = NULL (similarity + loss only)")
+    ap.add_argument("--no-wb", action="store_true", help="dw = db = NULL as well (the forward kernel's fast form of S)")
     ap.add_argument("--no-build", action="store_true", help="use the libge2e_hip_prof.so that is there (built off the GPU box)")
     ap.add_argument("--lib", default="libge2e_hip_prof.so", help="file name of the stamped library inside the package directory")
     args = ap.parse_args()
@@ -84,7 +86,7 @@ def main():
 
     def run():
         code = lib.ge2e_loss_fwd_bwd(E.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), 1e-8, 1e-6, v, im,
-                                     loss.data_ptr(), None, None if args.forward_only else dE.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                     loss.data_ptr(), None, None if args.forward_only else dE.data_ptr(), None if args.no_wb else dw.data_ptr(), None if args.no_wb else db.data_ptr(),
                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         assert code == 0, code
 
