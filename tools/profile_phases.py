@@ -41,10 +41,9 @@ PHASES = {
               "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: slice-1 reads + 24 MFMAs issued", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: pieces + slice-0 reads + 24 MFMAs issued",
               "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: slice-1 reads + 24 MFMAs issued", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: pieces + slice-0 reads + 24 MFMAs issued"],
     # the pipelined forward-only team kernel (csrc/ge2e_team_fwd.hip)
-    "team_fwd": ["poll c1(prev); A1(cur) speaker sum -> centroid published (prev's fragments requested underneath)",
-                 "A2(cur) compute half: norms, split halves in registers", "drain (vmcnt 0)", "barrier A + signal",
-                 "combine(prev - 1) [waves 4-7]; next rows requested; X(prev) contraction", "barrier B",
-                 "A2(cur) image writes; S(prev) [fast form: waves 0-3]", "-"],
+    "team_fwd": ["A1(cur) speaker sum -> centroid published; prev's fragments requested underneath", "X(prev) contraction -> XB",
+                 "drain (vmcnt 0)", "barrier 1 + signal", "A2(cur) rows -> images; rows of n + 2 requested", "S(prev) softmax, loss",
+                 "poll c1(cur) + barrier 2", "member scalars"],
     "fused_split": ["s1 centroids", "s2a stage", "s2b gemm1 X", "s2c softmax", "s2d KJP+gemm3 gC",
                     "finalize", "s3a stage+ring", "s3c gemm2", "s3d rows issue+barrier", "s3d epilogue body"],
 }
