@@ -49,7 +49,7 @@ extern "C" {
                                    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
 #define GE2E_IMPL_FUSED_SPLIT 3 /* as FUSED_F32 with fp16 hi+lo split operands on
                                    v_mfma_f32_32x32x16_f16, fp32 accumulate      */
-#define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B) */
+#define GE2E_IMPL_TILED 4       /* many workgroups per batch (large N / D, small B); D any multiple of 8 up to 1024 */
 #define GE2E_IMPL_TEAM 5        /* eight workgroups of one XCD per batch, the member's rows resident in LDS: E is
                                    read once.  ONE launch per call: if the teams cannot form or a hand-off times
                                    out, the same workgroups redo the call with FUSED_SPLIT's one-workgroup-per-batch

@@ -21,7 +21,7 @@
 // eight waves with two LDS stages -- register-staged (gemm_tile) or, when K is a multiple of 32, fed by
 // buffer_load ... lds with one workgroup per CU walking its tiles (gemm_tile_dma / walk_tiles, GemmCfgDma).
 //
-// Shapes: D % 64 == 0, D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
+// Shapes: D % 8 == 0 (rows of the fp16 planes 16-byte aligned; ragged K-steps and tiles are the cores' business), D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
 // Same algebra and same split arithmetic as ge2e_fused_split.hip.  Config 5 is bound by the contractions, config
 // 4 by the bytes the pipeline moves.
 #include "ge2e_common.hpp"
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(256) void ge2e_tiled_reduce(Problem p, TiledWs L) {
 
 // ---------------------------------------------------------------------------------------------
 bool tiled_supports(int N, int M, int D) {
-    return N >= 1 && N <= 1024 && M >= 2 && D >= 64 && D <= 1024 && (D % 64) == 0;
+    return N >= 1 && N <= 1024 && M >= 2 && D >= 8 && D <= 1024 && (D % 8) == 0;     // rows of the fp16 planes 16-byte aligned
 }
 
 TiledWs tiled_layout(int B, int N, int M, int D) {

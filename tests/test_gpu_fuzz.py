@@ -26,7 +26,7 @@ def cases(n, seed):
     while len(out) < n:
         N = int(rng.integers(1, 71))
         M = int(rng.integers(2, 17))
-        D = int(rng.choice([4, 20, 64, 96, 128, 192, 200, 256, 257, 320]))
+        D = int(rng.choice([4, 20, 64, 96, 128, 192, 200, 256, 257, 264, 320]))
         B = int(rng.integers(1, 600)) if N * M <= 64 and rng.random() < 0.5 else int(rng.integers(1, 12))
         if B * N * M * D > 6e6:      # keep the fp64 oracle quick
             continue
@@ -50,10 +50,11 @@ def test_random_shapes(GF, case):
         top2 = np.sort(S, axis=-1)[..., -2:]
         if N > 2 and float((top2[..., 1] - top2[..., 0]).min()) < 5e-6 * max(1.0, float(np.abs(top2[..., 1]).max())):
             pytest.skip("contrast: a row's two largest similarities tie within fp32 resolution")
-    # AUTO keeps the matrix-core kernels for every row-aligned D: no shape with 13 <= N <= 64, D <= 256, D % 4 == 0 may land on
-    # the VALU fall-back (85x slower than its neighbours).  Left to it: D % 4 != 0 (rows not 16-byte aligned), and N > 64 or
-    # D > 256 with D % 64 != 0 (the tiled pipeline's planes).
-    if 13 <= N <= 64 and D <= 256 and D % 4 == 0:
+    # AUTO keeps the matrix-core kernels for every row-aligned D: no shape with N >= 13 may land on the VALU fall-back (85x
+    # slower than its neighbours) when D % 4 == 0 (N <= 64, D <= 256: padded inside the team / one-workgroup kernels) or
+    # D % 8 == 0 (the tiled pipeline: rows of its fp16 planes 16-byte aligned).  Left to the fall-back: D % 4 != 0 (rows of E
+    # not 16-byte aligned), and D % 8 == 4 with N > 64 or D > 256.
+    if N >= 13 and ((N <= 64 and D <= 256 and D % 4 == 0) or (D <= 1024 and D % 8 == 0)):
         assert GF.resolve_impl(B, N, M, D, variant, "auto") != "generic", case
     seen = set()
     for impl in impls_for(GF, B, N, M, D, variant):

@@ -160,7 +160,9 @@ def test_config5_benched_launch_sampled(GF):
                                    (3, 8, 8, 256), (2, 6, 10, 256), (4, 3, 16, 256), (2, 7, 5, 32),
                                    # D that is no multiple of 64 (any multiple of 4 up to 256): zero-padded inside the
                                    # load / store stages of the team kernel and of the one-workgroup-per-batch kernel
-                                   (3, 64, 10, 200), (5, 40, 7, 80), (2, 20, 16, 4), (37, 64, 10, 132), (3, 9, 20, 100)])
+                                   (3, 64, 10, 200), (5, 40, 7, 80), (2, 20, 16, 4), (37, 64, 10, 132), (3, 9, 20, 100),
+                                   # ... and of the tiled pipeline (N > 64 or D > 256): any multiple of 8 (ragged K-steps and tiles)
+                                   (2, 130, 3, 72), (2, 256, 10, 200), (1, 300, 4, 264), (3, 100, 5, 40), (1, 520, 2, 776), (2, 64, 10, 328)])
 @pytest.mark.parametrize("variant", ["softmax", "contrast"])
 def test_ragged_shapes(GF, shape, variant):
     """Odd sizes: N not a multiple of the wave, D not a multiple of 4, M = 2, N = 1."""
@@ -171,6 +173,8 @@ def test_ragged_shapes(GF, shape, variant):
     impls = impls_for(GF, *shape, variant)
     if shape[3] % 4 == 0 and shape[3] <= 256 and 16 <= shape[1] <= 64 and shape[2] <= 16 and (shape[1] + 7) // 8 * shape[2] <= 80:
         assert "team" in impls and "fused_split" in impls, impls      # e.g. D = 200, D = 80: not the VALU kernel's business
+    if shape[3] % 8 == 0 and (shape[1] > 64 or shape[3] > 256):
+        assert "tiled" in impls and GF.resolve_impl(*shape, variant, "auto") == "tiled", impls
     for impl in impls:
         check(run_hip(GF, E, 7.5, -2.0, variant, impl), ref, impl, f"{shape}/{variant}/{impl}")
 
