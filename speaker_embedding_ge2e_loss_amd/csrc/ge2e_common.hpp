@@ -30,11 +30,8 @@ struct Problem {
     float eps;        // hp.general.small_err (1e-6)
     float log_eps;    // logf(eps), -inf when eps == 0
     unsigned long long* prof;  // diagnostic builds (-DGE2E_PROFILE) only: per-phase cycle sums
-    const unsigned* gate;      // non-null: the launch is a fall-back that runs only if *gate != 0 (ge2e_team.hip)
-    int grid_cap;              // > 0: at most this many workgroups (the fall-back's workspace is sized for it)
-    int test_abort;            // diagnostics: the team launch starts with its abort word raised (exercises the fall-back)
-    unsigned* cleanup_head;    // gated launch only: the team control block its last workgroup restores (ge2e_team.hpp) ...
-    int cleanup_n16;           // ... and its size in 16-byte pieces
+    int grid_cap;              // > 0: at most this many workgroups (diagnostics: the selftest launch, max_workgroups)
+    int test_abort;            // diagnostics: the team launch starts with its abort word raised (exercises the in-launch redo)
     // ge2e_loss_fwd_bwd_raw: E is the encoder's RAW projection Y [B][N*M][D] in its own (permuted) row order and
     // src [B][N*M] (or null = identity) says which row of Y is row r of the (N,M,D) block: the kernel normalises and gathers
     // in its load stage and writes dL/dY (through the normalisation's backward, scattered back) in its store stage.

@@ -231,6 +231,7 @@ __device__ __forceinline__ h8 gemm_frag(const _Float16* t, int blk0, int s, int 
 constexpr int DMA_PL = 32 * 256;            // halfs per plane
 constexpr int DMA_ST = 4 * DMA_PL;          // halfs per stage (64 KB)
 typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef float acc4 __attribute__((ext_vector_type(4)));   // a 16 x 16 accumulator block
 
 // per-lane byte offsets of this wave's two pieces (j = wave, wave + 8) of one operand's planes
 template <bool KC>
@@ -242,7 +243,8 @@ __device__ __forceinline__ void dma_piece_offsets(const Opnd& o, int lane, int w
             const int row = 16 * j + (lane >> 2), pc = (lane & 3) ^ ((lane >> 4) & 3);
             vo[jj] = row < o.valid ? (unsigned)(((size_t)row * o.ld + 8 * pc) * 2) : 0x7FFFFF00u;
         } else {    // piece = 2 K-rows x 512 B; lane -> row 2 j + lane / 32, LDS chunk position (lane & 31) / 4
-            const int row = 2 * j + (lane >> 5), ch = ((lane & 31) >> 2) ^ (row & 3), c8 = 32 * ch + 8 * (lane & 3);
+            const int row = 2 * j + (lane >> 5), ch = ((lane & 31) >> 2) ^ (row & 3);
+            const int c8 = 32 * ch + 8 * ((lane & 3) ^ ((row >> 2) & 2));
             vo[jj] = c8 < o.valid ? (unsigned)(((size_t)row * o.ld + c8) * 2) : 0x7FFFFF00u;
         }
     }
@@ -284,15 +286,14 @@ __device__ __forceinline__ void dma_wait_but(int n) {
     if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// fragment of 32-row / 32-column block `blk` (0..7 inside the tile) for K-slice s (16 K each) of a plane
+// fragment of 16-row / 16-column block `blk` (0..15 inside the tile) of a plane for v_mfma_f32_16x16x32_f16: lane
+// (i = lane % 16, kg = lane / 16) gets row / column i of the block, K = 8 kg .. 8 kg + 7 of the K-step
 template <bool KC>
-__device__ __forceinline__ h8 dma_frag(const _Float16* pl, int blk, int s, int lane) {
-    if (KC) {
-        const int l31 = lane & 31, g = (l31 >> 2) & 3, pc = ((lane >> 5) + 2 * s) ^ g;
-        return frag_row(pl + (32 * blk + l31) * 32 + 8 * pc);
-    }
-    const int hh = lane >> 5, g2 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
-    const _Float16* p = pl + (16 * s + 8 * hh + q) * 256 + 32 * (blk ^ q) + 16 * g2 + 4 * pp;
+__device__ __forceinline__ h8 dma_frag(const _Float16* pl, int blk, int lane) {
+    const int i = lane & 15, kg = lane >> 4;
+    if (KC) return frag_row(pl + (16 * blk + i) * 32 + 8 * (kg ^ ((i >> 2) & 3)));
+    const int q = i >> 2, pp = i & 3;     // the transposing read: lane 4 q + pp names K-row q, columns 4 pp .. 4 pp + 3
+    const _Float16* p = pl + (8 * kg + q) * 256 + 32 * ((blk >> 1) ^ q) + 16 * ((blk ^ kg) & 1) + 4 * pp;
     const h4 t0 = tr_read4(p);
     const h4 t1 = tr_read4(p + 4 * 256);
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -343,13 +344,19 @@ __device__ __forceinline__ void dma_run(const DmaJob& j, _Float16* sm, int tid, 
     const unsigned (&voA)[2] = j.voA;
     const unsigned (&voB)[2] = j.voB;
     const unsigned sm_byte = (unsigned)(unsigned long long)(lds_void_p)sm;
-    // Schedule of one K-step k (two 16-wide slices s0, s1; F0 / F1 = the twelve fragments of a slice, 48 VGPRs each):
-    //     read F1(k, s1)  |  24 MFMAs on F0(k, s0)      -- the reads return under the MFMAs
+    // The products run on v_mfma_f32_16x16x32_f16 (one MFMA = a whole K-step of a 16 x 16 block; tools/ubench/mfma_shapes.hip:
+    // with fragments coming from LDS it sustains 16-22 % more than 32x32x16, which needs the same fragment bytes but clocks
+    // ~250 MHz lower under the power cap).  A wave's 128 x 64 block = 8 A blocks x 4 B blocks, 96 MFMAs per K-step.
+    // Schedule of one K-step k (fragments: A 8 x (hi, lo), B 4 x (hi, lo) = 96 VGPRs, each register read once per K-step):
+    //     first half : A blocks 0-3 x B, A-major   |  behind group a: read A block 4 + a of stage k
     //     wait: own pieces of stage k + 1 landed; barrier  -- everybody has read all of stage k, stage k + 1 is whole
-    //     issue the pieces of K-step k + 2 into stage k's buffer
-    //     read F0(k + 1, s0)  |  24 MFMAs on F1(k, s1)
+    //     second half: A blocks 4-7 x B, B-major   |  behind group b: the pieces of K-step k + 2 into stage k's buffer, and
+    //                                                 B block b, A block b of stage k + 1 (B block b is done after group b)
     // A piece has a whole K-step (~1.3 us of MFMAs) to land, no fragment read is waited for with the matrix pipe idle, one
     // barrier per K-step.  The sched_barriers pin the order (left alone hipcc moves the barrier up to the first MFMA).
+    constexpr int A16 = 2 * C::A2, B16 = 2 * C::B2;
+    static_assert(A16 == 8 && B16 == 4, "schedule written for the 128 x 64 wave block");
+    const int a16 = 2 * ablk0, b16 = 2 * bblk0;
     const int nk = j.nk;
     unsigned kA = nk > 1 ? rA.kstep_bytes : 0u, kB = nk > 1 ? rB.kstep_bytes : 0u;
     if (nk > 1 && !drain_all) dma_wait_but(8);       // the eight pieces of step 0 (pieces land in issue order)
@@ -364,49 +371,45 @@ __device__ __forceinline__ void dma_run(const DmaJob& j, _Float16* sm, int tid, 
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    h8 f0a[C::A2][2], f0b[C::B2][2], f1a[C::A2][2], f1b[C::B2][2];
-    // A slice's twelve fragment reads come in three chunks (B and A block 0 | A blocks 1, 2 | A block 3) and its 24 MFMAs
-    // in four groups of six (one A block each); chunk c of the NEXT slice is issued behind MFMA group c of the current
-    // one, so that after a barrier the matrix pipe starts at once and every read / piece issues in the shadow of an MFMA
-    // (stamped build, round 4: with all reads and pieces issued in front of the MFMAs both waves of a SIMD left the
-    // pipe idle for ~700 cycles after every barrier).
-    auto read_chunk = [&](const _Float16* st, int s, int c, h8 (&fa)[C::A2][2], h8 (&fb)[C::B2][2]) {
-        if (c == 0) {
+    acc4 c16[A16][B16];
 #pragma unroll
-            for (int u = 0; u < C::B2; ++u) {
-                fb[u][0] = dma_frag<BKC>(st + 2 * DMA_PL, bblk0 + u, s, lane);
-                fb[u][1] = dma_frag<BKC>(st + 3 * DMA_PL, bblk0 + u, s, lane);
-            }
-        }
-        const int lo = c == 0 ? 0 : c == 1 ? 1 : 3, hi = c == 0 ? 1 : c == 1 ? 3 : 4;
+    for (int a = 0; a < A16; ++a)
 #pragma unroll
-        for (int a2 = 0; a2 < C::A2; ++a2)
-            if (a2 >= lo && a2 < hi) {
-                fa[a2][0] = dma_frag<AKC>(st, ablk0 + a2, s, lane);
-                fa[a2][1] = dma_frag<AKC>(st + DMA_PL, ablk0 + a2, s, lane);
-            }
+        for (int b = 0; b < B16; ++b) c16[a][b] = acc4{0.f, 0.f, 0.f, 0.f};
+    h8 fa[A16][2], fb[B16][2];
+    auto read_a = [&](const _Float16* st, int a) {
+        fa[a][0] = dma_frag<AKC>(st, a16 + a, lane);
+        fa[a][1] = dma_frag<AKC>(st + DMA_PL, a16 + a, lane);
     };
-    auto mfma_group = [&](int a2, const h8 (&fa)[C::A2][2], const h8 (&fb)[C::B2][2]) {
-#pragma unroll
-        for (int b2 = 0; b2 < C::B2; ++b2) acc[a2][b2] = mfma3(fa[a2][0], fa[a2][1], fb[b2][0], fb[b2][1], acc[a2][b2]);
+    auto read_b = [&](const _Float16* st, int b) {
+        fb[b][0] = dma_frag<BKC>(st + 2 * DMA_PL, b16 + b, lane);
+        fb[b][1] = dma_frag<BKC>(st + 3 * DMA_PL, b16 + b, lane);
+    };
+    auto mfma = [&](int a, int b) {
+        c16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a][0], fb[b][0], c16[a][b], 0, 0, 0);
+        c16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a][0], fb[b][1], c16[a][b], 0, 0, 0);
+        c16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a][1], fb[b][0], c16[a][b], 0, 0, 0);
     };
 #pragma unroll
-    for (int c = 0; c < 3; ++c) read_chunk(sm, 0, c, f0a, f0b);
+    for (int b = 0; b < B16; ++b) read_b(sm, b);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) read_a(sm, a);
     int cur = 0;
     for (int k = 0; k < nk; ++k, cur ^= 1) {
         const _Float16* const st = sm + cur * DMA_ST;
         const _Float16* const nx = sm + (cur ^ 1) * DMA_ST;
         const unsigned stage_byte = sm_byte + (unsigned)cur * (2u * DMA_ST);
 #pragma unroll
-        for (int a2 = 0; a2 < C::A2; ++a2) {          // slice 0 on the matrix pipe, slice 1 read behind it
-            if (a2 == 0) __builtin_amdgcn_s_setprio(1);
-            if (a2 == 2) __builtin_amdgcn_s_setprio(0);
-            mfma_group(a2, f0a, f0b);
+        for (int a = 0; a < 4; ++a) {                 // A blocks 0-3 on the matrix pipe, A blocks 4-7 read behind them
+            if (a == 0) __builtin_amdgcn_s_setprio(1);
+            if (a == 2) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int b = 0; b < B16; ++b) mfma(a, b);
             __builtin_amdgcn_sched_barrier(0);
-            if (a2 < 3) read_chunk(st, 1, a2, f1a, f1b);
+            read_a(st, 4 + a);
             __builtin_amdgcn_sched_barrier(0);
         }
-        DMA_STAMP(1);      // slice-1 reads + 24 MFMAs issued (the reads have returned)
+        DMA_STAMP(1);      // the reads of A blocks 4-7 + 48 MFMAs issued (the reads have returned)
         dma_wait();        // this wave's pieces of stage k + 1 have landed ...
         DMA_STAMP(2);
         __syncthreads();   // ... and so have everybody else's; everybody has read all of stage k
@@ -419,26 +422,27 @@ __device__ __forceinline__ void dma_run(const DmaJob& j, _Float16* sm, int tid, 
         // finishes its K-step ~1200 cycles early and sits at the barrier while the other runs alone with every read and
         // piece it issues exposed (stamped build, views of waves 0 and 4, round 4).
 #pragma unroll
-        for (int a2 = 0; a2 < C::A2; ++a2) {          // slice 1 on the matrix pipe; the pieces of K-step k + 2 (two per
-            if (a2 == 0) __builtin_amdgcn_s_setprio(3);   // group, into stage k's buffer) and slice 0 of step k + 1 behind it
-            if (a2 == 2) __builtin_amdgcn_s_setprio(2);
-            mfma_group(a2, f1a, f1b);
+        for (int b = 0; b < B16; ++b) {               // A blocks 4-7 on the matrix pipe, B-major; behind group b two pieces of
+            if (b == 0) __builtin_amdgcn_s_setprio(3);    // K-step k + 2 (into stage k's buffer) and B block b, A block b of step k + 1
+            if (b == 2) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int a = 4; a < A16; ++a) mfma(a, b);
             __builtin_amdgcn_sched_barrier(0);
             if (more2) {
-                const unsigned d = stage_byte + (unsigned)(wid + 8 * (a2 >> 1)) * 1024u;
-                if ((a2 & 1) == 0) {
-                    dma_piece(rA.hi, d, voA[a2 >> 1], kA);
-                    dma_piece(rA.lo, d + 2u * DMA_PL, voA[a2 >> 1], kA);
+                const unsigned d = stage_byte + (unsigned)(wid + 8 * (b >> 1)) * 1024u;
+                if ((b & 1) == 0) {
+                    dma_piece(rA.hi, d, voA[b >> 1], kA);
+                    dma_piece(rA.lo, d + 2u * DMA_PL, voA[b >> 1], kA);
                 } else {
-                    dma_piece(rB.hi, d + 4u * DMA_PL, voB[a2 >> 1], kB);
-                    dma_piece(rB.lo, d + 6u * DMA_PL, voB[a2 >> 1], kB);
+                    dma_piece(rB.hi, d + 4u * DMA_PL, voB[b >> 1], kB);
+                    dma_piece(rB.lo, d + 6u * DMA_PL, voB[b >> 1], kB);
                 }
             }
-            if (more1 && a2 < 3) read_chunk(nx, 0, a2, f0a, f0b);
+            if (more1) { read_b(nx, b); read_a(nx, b); }
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef GE2E_PROFILE
-        {   // 24 MFMAs + pieces + slice-0 reads issued; NOT waiting for the reads (they belong to the next step)
+        {   // 48 MFMAs + pieces + next step's reads issued; NOT waiting for the reads (they belong to the next step)
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();
             if (t_first) t_first[4] += now_ - last_;
@@ -448,6 +452,26 @@ __device__ __forceinline__ void dma_run(const DmaJob& j, _Float16* sm, int tid, 
 #endif
     }
     __builtin_amdgcn_s_setprio(0);
+    // The epilogues (and the register-staged loop) speak the 32 x 32 accumulator layout -- lane (h = lane / 32, c = lane % 32),
+    // register 4 g + j = row 8 g + 4 h + j, column c of the block.  A 16 x 16 accumulator has lane (r4 = lane / 16, c), register
+    // j = row 4 r4 + j.  Two gfx950 row swaps per register pair turn the four 16 x 16 blocks X[ar][bc] of a 32 x 32 block into
+    // it: v_permlane16_swap (X[ar][0], X[ar][1]) collects "h = 0 | h = 1" with lane rows (x, bc), v_permlane32_swap then
+    // collects "x = 0 | x = 1" (x = g % 2) with lane rows (h, bc).  128 swaps per wave and tile, no LDS, no barrier.
+#pragma unroll
+    for (int a2 = 0; a2 < C::A2; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < C::B2; ++b2)
+#pragma unroll
+            for (int ar = 0; ar < 2; ++ar)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float pv = c16[2 * a2 + ar][2 * b2][jj], qv = c16[2 * a2 + ar][2 * b2 + 1][jj];
+                    // (element copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.2)
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(pv), __float_as_uint(qv), false, false);
+                    const auto s2 = __builtin_amdgcn_permlane32_swap(s1[0], s1[1], false, false);
+                    acc[a2][b2][4 * (2 * ar) + jj] = __uint_as_float(s2[0]);
+                    acc[a2][b2][4 * (2 * ar + 1) + jj] = __uint_as_float(s2[1]);
+                }
 }
 template <class C, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile_dma(const Opnd& A, const Opnd& B, int ktotal, _Float16* sm, int tid,
