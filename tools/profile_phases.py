@@ -37,9 +37,9 @@ PHASES = {
               "A1c barrier", "A1d k-group form stores", "A1e drain (vmcnt 0)"],
     # the three contractions of the tiled pipeline (diagnostic slots 0.., 8.., 16..): wave 0's cycles per BATCH, summed over
     # the batch's tiles (cfg5: 160 similarity tiles, 12 gC tiles, 120 gE tiles per batch)
-    "tiled": ["sim: until the first stage landed", "sim: K loop", "sim: epilogue issued", "sim: stores drained", "sim loop: slice-1 reads + 24 MFMAs issued", "sim loop: own pieces landed", "sim loop: barrier", "sim loop: pieces + slice-0 reads + 24 MFMAs issued",
-              "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: slice-1 reads + 24 MFMAs issued", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: pieces + slice-0 reads + 24 MFMAs issued",
-              "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: slice-1 reads + 24 MFMAs issued", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: pieces + slice-0 reads + 24 MFMAs issued"],
+    "tiled": ["sim: until the first stage landed", "sim: K loop", "sim: epilogue issued", "sim: stores drained", "sim loop: A blocks 0-3 x B (48 MFMAs) + reads of A blocks 4-7", "sim loop: own pieces landed", "sim loop: barrier", "sim loop: A blocks 4-7 x B (48 MFMAs) + pieces + next step's reads",
+              "gc: until the first stage landed", "gc: K loop", "gc: epilogue issued", "gc: stores drained", "gc loop: A blocks 0-3 x B (48 MFMAs) + reads of A blocks 4-7", "gc loop: own pieces landed", "gc loop: barrier", "gc loop: A blocks 4-7 x B (48 MFMAs) + pieces + next step's reads",
+              "ge: until the first stage landed", "ge: K loop", "ge: epilogue issued", "ge: stores drained", "ge loop: A blocks 0-3 x B (48 MFMAs) + reads of A blocks 4-7", "ge loop: own pieces landed", "ge loop: barrier", "ge loop: A blocks 4-7 x B (48 MFMAs) + pieces + next step's reads"],
     # the pipelined forward-only team kernel (csrc/ge2e_team_fwd.hip)
     "team_fwd": ["A1(cur) speaker sum -> centroid published; prev's fragments requested underneath", "X(prev) contraction -> XB",
                  "drain (vmcnt 0)", "barrier 1 + signal", "A2(cur) rows -> images; rows of n + 2 requested", "S(prev) softmax, loss",
