@@ -224,15 +224,22 @@ __device__ __forceinline__ h8 gemm_frag(const _Float16* t, int blk0, int s, int 
 // LDS bytes are lane-linear (that is what the instruction does), so the images are unpadded and the bank spread comes
 // from which GLOBAL 16 bytes a lane fetches (the read side applies the same exclusive-or):
 //   K-rows plane  [32 K-rows][256 cols]: 512-byte rows; 64-byte column chunk c of row r sits at chunk position c ^ (r & 3)
-//                 -- the transposing read's four rows of one half-wave land on four different quarter rows of the banks;
-//   K-contig plane [256 rows][32 K]:     64-byte rows; 16-byte piece p of row r sits at piece position p ^ ((r >> 2) & 3)
-//                 -- the sixteen rows of a ds_read_b128 lane group land on sixteen different 16-byte slots.
+//                 and the two 32-byte halves of a chunk are exchanged in K-rows 8-15 and 24-31 -- a half-wave of the 16-lane
+//                 transposing read covers K-rows {q, 8 + q}, q = 0..3: eight different 32-byte slots of a bank row;
+//   K-contig plane [256 rows][32 K]:     64-byte rows; 16-byte piece p of row r sits at piece position p ^ kc_swizzle(r % 16)
+//                 = p ^ (bit 2 of r, bit 1 of r).  ds_read_b128 does not take its lanes sixteen consecutive ones at a time:
+//                 with the first form's (bit 3, bit 2) the 16-row fragments of the 16x16x32 MFMA (lane = row i, K group kg:
+//                 piece kg ^ f(i)) collided two-way although sixteen consecutive lanes hit sixteen different slots
+//                 (SQ_LDS_BANK_CONFLICT = half of k_sim's LDS cycles); tools/ubench/lds_b128_banks.hip times all 256
+//                 linear choices of f -- this one is among the conflict-free ones, and the counter is 0 again.
 // Needs ktotal % 32 == 0 (a K-contiguous piece past the end of K would read the next row); other shapes keep the loop above.
 constexpr int DMA_PL = 32 * 256;            // halfs per plane
 constexpr int DMA_ST = 4 * DMA_PL;          // halfs per stage (64 KB)
 typedef __attribute__((address_space(3))) void* lds_void_p;
 typedef float acc4 __attribute__((ext_vector_type(4)));   // a 16 x 16 accumulator block
 
+// K-contiguous plane: the piece position of row r's piece p is p ^ kc_swizzle(r % 16)
+__device__ __forceinline__ int kc_swizzle(int r) { return (r >> 1) & 3; }
 // per-lane byte offsets of this wave's two pieces (j = wave, wave + 8) of one operand's planes
 template <bool KC>
 __device__ __forceinline__ void dma_piece_offsets(const Opnd& o, int lane, int wid, unsigned (&vo)[2]) {
@@ -240,7 +247,7 @@ __device__ __forceinline__ void dma_piece_offsets(const Opnd& o, int lane, int w
     for (int jj = 0; jj < 2; ++jj) {
         const int j = wid + 8 * jj;
         if (KC) {   // piece = 16 rows x 64 B; lane -> row 16 j + lane / 4, LDS piece position lane & 3
-            const int row = 16 * j + (lane >> 2), pc = (lane & 3) ^ ((lane >> 4) & 3);
+            const int row = 16 * j + (lane >> 2), pc = (lane & 3) ^ kc_swizzle(lane >> 2);
             vo[jj] = row < o.valid ? (unsigned)(((size_t)row * o.ld + 8 * pc) * 2) : 0x7FFFFF00u;
         } else {    // piece = 2 K-rows x 512 B; lane -> row 2 j + lane / 32, LDS chunk position (lane & 31) / 4
             const int row = 2 * j + (lane >> 5), ch = ((lane & 31) >> 2) ^ (row & 3);
@@ -291,7 +298,7 @@ __device__ __forceinline__ void dma_wait_but(int n) {
 template <bool KC>
 __device__ __forceinline__ h8 dma_frag(const _Float16* pl, int blk, int lane) {
     const int i = lane & 15, kg = lane >> 4;
-    if (KC) return frag_row(pl + (16 * blk + i) * 32 + 8 * (kg ^ ((i >> 2) & 3)));
+    if (KC) return frag_row(pl + (16 * blk + i) * 32 + 8 * (kg ^ kc_swizzle(i)));
     const int q = i >> 2, pp = i & 3;     // the transposing read: lane 4 q + pp names K-row q, columns 4 pp .. 4 pp + 3
     const _Float16* p = pl + (8 * kg + q) * 256 + 32 * ((blk >> 1) ^ q) + 16 * ((blk ^ kg) & 1) + 4 * pp;
     const h4 t0 = tr_read4(p);
