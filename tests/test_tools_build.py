@@ -1,0 +1,21 @@
+"""The micro-benchmarks under tools/ubench/ are evidence sources (DESIGN.md cites their numbers): they have to keep
+compiling for gfx950 with the image's hipcc.  Device code only, no GPU needed."""
+import glob
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.hip")))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+@pytest.mark.parametrize("src", SOURCES, ids=[os.path.basename(s) for s in SOURCES])
+def test_micro_benchmark_compiles_for_gfx950(src, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    inc = os.path.join(ROOT, "speaker_embedding_ge2e_loss_amd", "csrc")       # mix_split_test checks the kernels' own helper
+    out = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", inc, "-c", "-o", str(tmp_path / "x.o"), src],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
