@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """GE2E loss+backward throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--impl auto] [--mode loss|train-step]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The reference's train -> test-loss -> EER flow (train_embedding_model.py / test_embedding_model.py) on synthetic
 speakers, with every hot piece on the GPU.  One process per GPU:
 

@@ -244,6 +244,13 @@ int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, cons
                                 float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with the abort word raised by ONE workgroup (block index grid / 2) when it reaches the end of the launch: the
+ * workgroups that finished before leave, the later ones stay, and the redo must agree on its size (TeamCtl::go).  dE may be
+ * NULL (the forward-only team kernel).  Same arguments and results. */
+int ge2e_selftest_team_abort_midgrid(const float* E, int B, int N, int M, int D, const float* w, const float* b,
+                                     float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
+                                     float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ge2e_loss_fwd_bwd with impl = GE2E_IMPL_TEAM on at most max_workgroups workgroups (>= 64, rounded down to a multiple
  * of 64 = one team per XCD): the same results from fewer teams, i.e. many more batches through each team's hand-off
  * counters than a full-size launch reaches. */

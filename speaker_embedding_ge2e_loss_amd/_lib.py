@@ -65,6 +65,8 @@ PROTOTYPES = {
     "ge2e_sample_batch": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ge2e_selftest_team_fallback": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
                                               C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ge2e_selftest_team_abort_midgrid": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
+                                                   C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ge2e_selftest_team_grid": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float,
                                           C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp, C.c_int]),
 }

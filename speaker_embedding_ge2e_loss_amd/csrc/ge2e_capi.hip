@@ -345,6 +345,20 @@ int ge2e_selftest_team_fallback(const float* E, int B, int N, int M, int D, cons
     return run(p, GE2E_IMPL_TEAM, workspace, workspace_bytes, stream);
 }
 
+// GE2E_IMPL_TEAM with the abort word raised by one workgroup in the middle of the grid's finish (some leave, some stay)
+int ge2e_selftest_team_abort_midgrid(const float* E, int B, int N, int M, int D, const float* w, const float* b,
+                                     float eps_cos, float eps, int variant, float* loss, float* per_emb_loss, float* dE,
+                                     float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!E || !w || !b || !loss) return GE2E_ERR_NULL;
+    if (dE && (!dw || !db)) return GE2E_ERR_NULL;
+    Problem p{};
+    p.E = E; p.w = w; p.b = b; p.loss = loss; p.per = per_emb_loss;
+    p.dE = dE; p.dw = dw; p.db = db; p.cos_out = nullptr;
+    p.B = B; p.N = N; p.M = M; p.D = D; p.variant = variant; p.eps_cos = eps_cos; p.eps = eps;
+    p.test_abort = 2;
+    return run(p, GE2E_IMPL_TEAM, workspace, workspace_bytes, stream);
+}
+
 // GE2E_IMPL_TEAM on at most `max_workgroups` workgroups (a multiple of 64: eight per XCD form one team): many batches
 // through few teams, so that the hand-off counters of a team run far beyond what a full-size launch reaches.
 int ge2e_selftest_team_grid(const float* E, int B, int N, int M, int D, const float* w, const float* b, float eps_cos,

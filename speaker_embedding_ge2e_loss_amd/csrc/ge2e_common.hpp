@@ -31,7 +31,9 @@ struct Problem {
     float log_eps;    // logf(eps), -inf when eps == 0
     unsigned long long* prof;  // diagnostic builds (-DGE2E_PROFILE) only: per-phase cycle sums
     int grid_cap;              // > 0: at most this many workgroups (diagnostics: the selftest launch, max_workgroups)
-    int test_abort;            // diagnostics: the team launch starts with its abort word raised (exercises the in-launch redo)
+    int test_abort;            // diagnostics: 1 = the team launch starts with its abort word raised (every workgroup stays for the
+                               // in-launch redo); 2 = ONE workgroup raises it when it reaches the end of the launch (some leave, some stay)
+    unsigned launch_seq;       // team launches: the host's number of this launch (never 0), see TeamCtl::gen
     // ge2e_loss_fwd_bwd_raw: E is the encoder's RAW projection Y [B][N*M][D] in its own (permuted) row order and
     // src [B][N*M] (or null = identity) says which row of Y is row r of the (N,M,D) block: the kernel normalises and gathers
     // in its load stage and writes dL/dY (through the normalisation's backward, scattered back) in its store stage.

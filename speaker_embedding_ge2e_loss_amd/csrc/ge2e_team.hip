@@ -34,6 +34,7 @@
 #include "ge2e_team_kernel.hpp"
 #include "ge2e_team_dev.hpp"
 #include "ge2e_fused.hpp"
+#include <atomic>
 
 namespace ge2e {
 
@@ -153,11 +154,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L,
 
     TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
     TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
-    const TeamId id = team_form(ctl, SH);
+    const TeamId id = team_form(ctl, SH, p.launch_seq);
     if (id.team == -2) {    // a control block that cannot be trusted: no counters at all -- static redo, workgroup 0 leaves a clean block
         team_redo<NCH>(p, L, F, smem_f, (int)gridDim.x, (int)blockIdx.x);
         __syncthreads();
-        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u);
+        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u, p.launch_seq);
         return;
     }
     if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the call is redone at the end of this launch
@@ -929,6 +930,10 @@ _Pragma("unroll")                                                               
     //      the control block back clean; with the abort word up the workgroups that are still there redo the call with the
     //      one-workgroup-per-batch body
     {
+        if (p.test_abort == 2 && blockIdx.x == (gridDim.x >> 1)) {   // diagnostics: the word rises in the middle of the grid's finish
+            if (tid == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+        }
         int* const fsh = reinterpret_cast<int*>(smem_f) + 4;     // (LDS is free now: every wave of this workgroup is here)
         const TeamRedo rd = team_finish(ctl, fsh, (int)(L.head_bytes / 16), gave_up);
         if (rd.n != 0) {
@@ -970,7 +975,7 @@ static hipError_t launch_nch(Problem& p, TeamKWs& L, const FusedWs& F, hipStream
     // ONE launch per call: the control block is self-cleaning (ge2e_team.hpp) -- the previous call's last workgroup left it
     // clean, ge2e_workspace_init wrote a first clean one, and anything else makes this launch redo itself without teams
     // and leave a clean block.  (p.test_abort: diagnostics, a block with the abort word raised is written in front.)
-    if (p.test_abort) {
+    if (p.test_abort == 1) {
         err = launch_team_head_init(p.ws, L.head_bytes, true, stream);
         if (err != hipSuccess) return err;
     }
@@ -997,6 +1002,12 @@ static hipError_t launch_variant(Problem& p, TeamKWs& L, const FusedWs& F, hipSt
 
 hipError_t launch_team(const Problem& p_in, hipStream_t stream) {
     Problem p = p_in;
+    {   // TeamCtl::gen: a number per launch, never 0 (a HIP graph replays the number it captured: a replay that finds an
+        // untrusted block redoes itself without counters every time until another launch or ge2e_workspace_init cleans it)
+        static std::atomic<unsigned> seq{0};
+        unsigned s = seq.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        p.launch_seq = s ? s : seq.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    }
     TeamKWs L = team_layout(p.N, p.M, p.D);
     const FusedWs F = fused_split_layout(p.N, p.M, p.D);
     // the redo body's slices behind the teams' exchange areas; its LDS if that is larger than the team kernel's

@@ -54,20 +54,33 @@ struct TeamCtl {
     unsigned magic;     unsigned pad4[31];              // TEAM_MAGIC <=> the rest of the block (and the team flags) is zero
     unsigned fallbacks; unsigned pad5[31];              // diagnostic, survives the clean-up: calls on this workspace whose abort
                                                         // word was up (no team formed, a hand-off timed out, unclean block)
-    unsigned seen;      unsigned pad6[31];              // workgroups that have read the abort word at the end (team_finish)
+    unsigned seen;      unsigned pad6[31];              // workgroups that have found the abort word up at the end (team_finish): ranks
+    unsigned go;        unsigned pad7[31];              // the redo's size, decided ONCE: 0 = not yet, TEAM_GO_LONE = every stayer by
+                                                        // itself, else n = the final `seen` (stored by the last finisher)
+    unsigned redo_done; unsigned pad8[31];              // workgroups of the redo that have finished it (team_redo_done)
+    unsigned gen;       unsigned pad9[31];              // != 0: the launch (Problem::launch_seq) whose workgroup 0 wrote this block
+                                                        // after a redo WITHOUT counters; that launch's own late workgroups must
+                                                        // not take the block for a clean one (team_form)
 };
+constexpr unsigned TEAM_GO_LONE = 0xFFFFFFFFu;
 constexpr unsigned long long TEAM_FINISH_TICKS = 5000000ull;    // 50 ms: the whole grid has finished (every inner wait is bounded
                                                                 // by 4 ms and gives up as soon as the abort word rises)
 // bytes of the control block + 64 per-team flag records (shape-independent; TeamKFlags = 3 lines, TeamFlags = 2)
 constexpr size_t team_head_bytes() { return (sizeof(TeamCtl) + 64 * 3 * 128 + 255) / 256 * 256; }
 // zero `bytes` at `head` (a multiple of 16) and set the magic (and, for diagnostics, the abort word): one small launch
 hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hipStream_t stream);
-// a clean block (zeros + magic + the surviving fall-back count) over `n16` 16-byte pieces; called by one wave (64 threads)
-__device__ __forceinline__ void team_head_rewrite(unsigned* head, int n16, unsigned fallbacks) {
+// a clean block (zeros + magic + the surviving fall-back count) over `n16` 16-byte pieces; called by one wave (64 threads).
+// `gen` != 0 marks the block as written by that launch's redo without counters (TeamCtl::gen).
+__device__ __forceinline__ void team_head_rewrite(unsigned* head, int n16, unsigned fallbacks, unsigned gen = 0u) {
     constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
+    constexpr int gen_piece = (int)(offsetof(TeamCtl, gen) / 16);
     uint4* h16 = reinterpret_cast<uint4*>(head);
     for (int i = threadIdx.x & 63; i < n16; i += 64)
-        h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fallbacks : 0u), 0u, 0u, 0u);
+        if (i != magic_piece)
+            h16[i] = make_uint4(i == fb_piece ? fallbacks : (i == gen_piece ? gen : 0u), 0u, 0u, 0u);
+    // the magic goes last, behind the rest of the block: a reader that finds it finds the zeros (and `gen`) too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) h16[magic_piece] = make_uint4(TEAM_MAGIC, 0u, 0u, 0u);
 }
 struct TeamFlags {                                      // per team
     unsigned c1;        unsigned pad0[31];              // hand-off 1 (unit centroids published)
@@ -109,8 +122,16 @@ __device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, T
 }
 
 // Called by all threads of the workgroup; `sh` is 4 ints of LDS.  Contains workgroup barriers.
-__device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
-    if (threadIdx.x == 0 && ld_poll(&ctl->magic) != TEAM_MAGIC) {
+// `launch_seq`: the host's number of this launch (0 = none): a block whose `gen` carries it was written by workgroup 0 of THIS
+// launch at the end of a redo without counters -- to a workgroup of the same launch that starts late it is as untrusted as
+// the block workgroup 0 found (it would otherwise form a team by itself, wait 2 ms, raise the abort word and wait 50 ms).
+__device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh, unsigned launch_seq = 0u) {
+    bool trusted = false;
+    if (threadIdx.x == 0) {
+        trusted = ld_poll(&ctl->magic) == TEAM_MAGIC;
+        if (trusted && launch_seq != 0u) trusted = ld_poll(&ctl->gen) != launch_seq;
+    }
+    if (threadIdx.x == 0 && !trusted) {
         // not a clean control block (fresh or overwritten memory): no counter in it can be trusted, so no teams and no
         // end-of-grid protocol either -- the caller redoes the call with a static split and workgroup 0 writes a clean block
         sh[0] = -2; sh[1] = 0; sh[2] = 0;
@@ -138,71 +159,88 @@ __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh) {
     return id;
 }
 
-// one lane: wait until *p >= target whatever the abort word says (the end-of-grid wait)
-__device__ __forceinline__ bool spin_until_all(const unsigned* p, unsigned target, unsigned long long ticks) {
-    if ((int)(ld_poll(p) - target) >= 0) return true;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned it = 0;; ++it) {
-        if ((int)(ld_poll(p) - target) >= 0) return true;
-        if ((it & 63) == 63 && __builtin_amdgcn_s_memrealtime() - t0 > ticks) return false;
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
 // End of a team launch on a TRUSTED control block, called by all threads of every workgroup (also the ones without a team or
 // without a batch).  The common case costs one load and one atomic and waits for nobody: a workgroup that finds the abort
 // word down counts itself in `done` and leaves; the one that completes the count rewrites the block (everybody else has
 // left).  A workgroup that finds the abort word UP takes a rank in `seen`, counts itself in `done` as well and STAYS until
-// the count is complete; the last finisher joins them if the word is up by then (it may have risen late).  Those that stayed
+// the last finisher has published how many of them there are (`go`).  Those that stayed
 // redo the call with the one-workgroup-per-batch body, batches rank, rank + n, ...: all of the grid when no team could
 // form (the word is up before anybody finishes), at least the team whose hand-off ran out otherwise.  Returns the number of
 // workgroups in the redo (0: none, leave) and this workgroup's rank; the caller ends with team_redo_done().
 // `sh`: 4 ints of LDS.  `n16`: size of the control block + flags in 16-byte pieces.
 struct TeamRedo { int n, rank; };
+__device__ __forceinline__ unsigned cas_agent(unsigned* p, unsigned expected, unsigned desired) {   // returns what was there
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+// The size of the redo is decided ONCE, by the last finisher, and published in `go` (round 6; until then every stayer read
+// `seen` for itself once `done` was complete -- but a last finisher that found the word risen late bumped `seen` AFTER
+// that, and nothing ordered a stayer's two relaxed adds: stayers could leave with different n, and strides rank, rank + n,
+// ... over different n do not tile the batches):
+//   * a workgroup that stays takes its rank in `seen`, WAITS for that add (s_waitcnt vmcnt(0), as team_form does between its
+//     two adds) and only then counts itself in `done`;
+//   * the workgroup whose `done` add completes the grid therefore reads the final `seen`.  It stores it in `go` -- or, with
+//     nobody staying, rewrites the block.  If it finds the abort word risen only now it does NOT join: whoever raised the
+//     word stays, and the stayers cover every batch;
+//   * stayers spin on `go`.  A stayer whose wait runs out (50 ms: a workgroup of this grid has not finished) moves `go` from
+//     0 to TEAM_GO_LONE -- a compare-and-swap, so that either EVERY stayer redoes the call alone in the slice of its own block
+//     index, or every stayer takes part in the ranked redo; the two never mix (they would share workspace slices).
 // `known_up`: this workgroup knows the word is (being) raised -- no team formed anywhere, or its own hand-off ran out.
 __device__ __forceinline__ TeamRedo team_finish(TeamCtl* ctl, int* sh, int n16, bool known_up) {
     __syncthreads();
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this workgroup's results are out
         int n = 0, rank = 0, clean = 0;
-        unsigned up = ld_poll(&ctl->abort_) | (known_up ? 1u : 0u);
-        if (up) rank = (int)add_agent(&ctl->seen, 1u);              // (returned before `done` moves: the two are ordered)
-        const bool last = add_agent(&ctl->done, 1u) == gridDim.x - 1;
-        if (!up && last) {
-            up = ld_poll(&ctl->abort_);                             // final: everybody else has finished
-            if (up) rank = (int)add_agent(&ctl->seen, 1u);
-            else clean = 1;
-        }
+        const unsigned up = ld_poll(&ctl->abort_) | (known_up ? 1u : 0u);
         if (up) {
-            if (last || spin_until_all(&ctl->done, gridDim.x, TEAM_FINISH_TICKS)) {
-                n = (int)ld_poll(&ctl->seen);                       // every stayer took its rank before it counted in `done`
-            } else {
-                // a workgroup of this grid has not finished within 50 ms: nothing about the block holds any more.  Take the
-                // magic away (the next call redoes itself without counters and writes a fresh block) and redo ALONE.
-                __hip_atomic_store(&ctl->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                n = -1;
+            rank = (int)add_agent(&ctl->seen, 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the rank is taken before `done` moves
+        }
+        const bool last = add_agent(&ctl->done, 1u) == gridDim.x - 1;
+        unsigned g = 0u;
+        if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned s = ld_poll(&ctl->seen);                 // final: every other workgroup has left or holds its rank
+            if (s == 0u) clean = 1;                                 // nobody stays (up implies s >= 1)
+            else {
+                g = cas_agent(&ctl->go, 0u, s);                     // 0 -> n; a stayer may have declared TEAM_GO_LONE meanwhile
+                if (g == 0u) g = s;
             }
+        } else if (up) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned it = 0; (g = ld_poll(&ctl->go)) == 0u; ++it) {
+                if ((it & 63) == 63 && __builtin_amdgcn_s_memrealtime() - t0 > TEAM_FINISH_TICKS) {
+                    g = cas_agent(&ctl->go, 0u, TEAM_GO_LONE);
+                    if (g == 0u) g = TEAM_GO_LONE;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (up && g == TEAM_GO_LONE) {
+            // a workgroup of this grid has not finished within 50 ms: nothing about the block holds any more.  Take the
+            // magic away (the next call redoes itself without counters and writes a fresh block) and redo ALONE.
+            __hip_atomic_store(&ctl->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n = -1;
+        } else if (up) {
+            n = (int)g;
         }
         sh[0] = n; sh[1] = rank; sh[2] = clean;
     }
     __syncthreads();
     TeamRedo r{sh[0], sh[1]};
-    if (sh[2]) {                                                    // nobody else is left: a clean block for the next call
-        const unsigned fb = ctl->fallbacks;
-        constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
-        uint4* h16 = reinterpret_cast<uint4*>(ctl);
-        for (int i = threadIdx.x; i < n16; i += blockDim.x)
-            h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fb : 0u), 0u, 0u, 0u);
-    }
+    if (sh[2] && threadIdx.x < 64)                                  // nobody else is left: a clean block for the next call
+        team_head_rewrite(reinterpret_cast<unsigned*>(ctl), n16, ctl->fallbacks);
     return r;
 }
-// ... after the redo: the last of its workgroups rewrites the block (the `nct` word counts them; it is diagnostic otherwise)
+// ... after the ranked redo: the last of its n workgroups rewrites the block (`redo_done` counts them; n is the same for all of
+// them, so exactly one add returns n - 1 and `fallbacks` has a single writer)
 __device__ __forceinline__ void team_redo_done(TeamCtl* ctl, int* sh, int n16, int n) {
     __syncthreads();
     if (n < 0) return;                                              // redone alone, the block is marked untrusted
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sh[0] = add_agent(&ctl->xcd_count[0][1], 1u) == (unsigned)(n - 1) ? 1 : 0;
+        sh[0] = add_agent(&ctl->redo_done, 1u) == (unsigned)(n - 1) ? 1 : 0;
     }
     __syncthreads();
     if (sh[0] && threadIdx.x < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), n16, ctl->fallbacks + 1u);

@@ -71,11 +71,11 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
 
     TeamCtl* const ctl = reinterpret_cast<TeamCtl*>(p.ws);
     TeamKFlags* const flags = reinterpret_cast<TeamKFlags*>(ctl + 1);
-    const TeamId id = team_form(ctl, SH);
+    const TeamId id = team_form(ctl, SH, p.launch_seq);
     if (id.team == -2) {    // a control block that cannot be trusted: no counters at all -- static redo, workgroup 0 leaves a clean block
         team_redo<NCH>(p, L, F, smem_f, (int)gridDim.x, (int)blockIdx.x);
         __syncthreads();
-        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u);
+        if (blockIdx.x == 0 && tid < 64) team_head_rewrite(reinterpret_cast<unsigned*>(ctl), (int)(L.head_bytes / 16), 1u, p.launch_seq);
         return;
     }
     if (id.nct == 0 && blockIdx.x == 0 && tid == 0)   // no eight workgroups share an XCD: the call is redone at the end of this launch
@@ -596,6 +596,10 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_fwd_kernel(Problem p, TeamKW
     // ---- end of the launch (team_finish, ge2e_team.hpp): one load and one atomic in the common case, the last workgroup hands
     //      the control block back clean; with the abort word up the workgroups that are still there redo the call
     {
+        if (p.test_abort == 2 && blockIdx.x == (gridDim.x >> 1)) {   // diagnostics: the word rises in the middle of the grid's finish
+            if (threadIdx.x == 0) __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+        }
         int* const fsh = reinterpret_cast<int*>(smem_f) + 4;
         const TeamRedo rd = team_finish(ctl, fsh, (int)(L.head_bytes / 16), gave_up);
         if (rd.n != 0) {
@@ -617,7 +621,7 @@ static hipError_t launch_fwd_nch(Problem& p, TeamKWs& L, const FusedWs& F, hipSt
     int nb = 0;
     hipError_t err = prepare_kernel(state, fn, 512, lds, &nb);
     if (err != hipSuccess) return err;
-    if (p.test_abort) {
+    if (p.test_abort == 1) {
         err = launch_team_head_init(p.ws, L.head_bytes, true, stream);
         if (err != hipSuccess) return err;
     }

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Equal-error-rate fixtures from the reference's own ``calculate_ERR`` (build container only).
 
     python tests/golden/make_eer_golden.py

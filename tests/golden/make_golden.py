@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate golden vectors by importing the reference's own GE2ELoss on CPU.
 
 Run in the build container only (needs /root/reference):

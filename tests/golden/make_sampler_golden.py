@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Sampler fixtures from the reference's own dataset class (build container only).
 
     python tests/golden/make_sampler_golden.py

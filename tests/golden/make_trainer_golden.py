@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Capture SGD loss trajectories from the reference's own encoder + loss (build container only).
 
     python tests/golden/make_trainer_golden.py

@@ -122,6 +122,43 @@ def test_fallback_when_no_team_forms(GF):
             assert rel_fro(dE[i].cpu().numpy(), ref["dE"][i]) < 2e-5, (B, i)
 
 
+def test_abort_raised_in_the_middle_of_the_grid(GF):
+    """ONE workgroup raises the abort word when it reaches the end of the launch: the workgroups that finished before it have
+    left, the later ones stay -- the redo's size is decided once (TeamCtl.go, by the last finisher), so the stayers' strides
+    tile the batches whatever each of them saw.  Outputs are NaN-poisoned: a batch nobody redid, or wrote half, shows.
+    Afterwards the control block must be clean: the next ordinary call forms its teams and counts no further fall-back."""
+    from speaker_embedding_ge2e_loss_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    for (B, N, M, D), fwd_only in (((70, 64, 10, 256), False), ((300, 64, 10, 256), False), ((9, 23, 7, 128), False),
+                                   ((70, 64, 10, 256), True), ((33, 40, 6, 192), True)):
+        E = orc.synth_embeddings((B, N, M, D), "unit", seed=B + N)
+        ref = orc.closed_form(E, 10.0, -5.0)
+        e = torch.as_tensor(E, device=dev)
+        w, b = torch.tensor(10.0, device=dev), torch.tensor(-5.0, device=dev)
+        nan = lambda *s: torch.full(s, float("nan"), device=dev)  # noqa: E731
+        ws = GF.alloc_workspace(GF.workspace_bytes(B, N, M, D, "softmax", "team"), dev)
+        for rep in range(3):
+            loss, dE, dw, db = nan(B), nan(B, N, M, D), nan(B), nan(B)
+            rc = lib.ge2e_selftest_team_abort_midgrid(e.data_ptr(), B, N, M, D, w.data_ptr(), b.data_ptr(), 1e-8, 1e-6, 0,
+                                                      loss.data_ptr(), None, None if fwd_only else dE.data_ptr(),
+                                                      None if fwd_only else dw.data_ptr(), None if fwd_only else db.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert np.allclose(loss.cpu().numpy(), ref["loss"], rtol=2e-5), (B, N, rep)
+            if not fwd_only:
+                assert np.allclose(dw.cpu().numpy(), ref["dw"], rtol=1e-4, atol=1e-4)
+                for i in range(B):
+                    assert rel_fro(dE[i].cpu().numpy(), ref["dE"][i]) < 2e-5, (B, i, rep)
+            assert GF.workspace_fallback_count(ws) == rep + 1          # counted once per call, by a single writer
+        # the block was left clean: an ordinary call on the same workspace runs with teams
+        o = GF.loss_fwd_bwd(e, w, b, impl="team", workspace=ws, need_grad=not fwd_only)
+        torch.cuda.synchronize()
+        assert np.allclose(o.loss.cpu().numpy(), ref["loss"], rtol=2e-5)
+        assert GF.workspace_fallback_count(ws) == 3
+
+
 def test_team_beside_a_busy_stream(GF):
     """A long-running kernel on a second stream holds CUs while the team launch goes out (its workgroups wait for each
     other): the result must still be finite and correct, through the team kernel or through its fall-back."""

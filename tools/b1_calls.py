@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Single-batch calls back to back (the bench's latency_b1 leg on its own, for a kernel trace):
 rocprofv3 --kernel-trace --stats -d gpurun_out/b1 -- python3 tools/b1_calls.py [impl]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """One line per committed bench line of a round: value, roofline fraction, traffic ratio, forward-only leg, latencies.
 Usage: python tools/bench_summary.py [r04]"""
 import glob

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the team hand-off (ge2e_team.hpp) in isolation: rounds of publish -> signal -> wait -> read all.
 Usage (GPU box): python tools/bench_team_handoff.py"""
 import os

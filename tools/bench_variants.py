@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development aid: build experiment variants of the library (extra -D definitions, same per-source flags as the
 product build), and for each run a parity probe and the cfg2 bench in a child process.
 Usage (GPU box): python tools/bench_variants.py "<defs of variant 1>" "<defs of variant 2>" ...   ("" = product flags)"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Quick parity probe of one implementation against the oracle (development aid).
 Usage (GPU box): python tools/check_team.py [impl] [B N M D] [variant]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Interleaved timing of implementations in ONE process (cdna_hip_programming.md rule 24): cfg2, several B.
 usage: python tools/compare_impls.py [impl ...]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Debug aid: one TILED launch at a shape that takes the LDS-DMA kernels, each output against the fp64 oracle, with the
 structure of the dE error (which rows / columns are off).  usage: python tools/dbg_tiled.py [B N M D]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing experiment: cache-policy bits (0 default, 2 nt, 1 sc0, 16 sc1) on the three E streams of fused_split.
 Usage (GPU box): python tools/exp_cache_policy.py"""
 import ctypes as C

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Static instruction mix per phase of a kernel's -save-temps assembly (development aid, no GPU).
 
 Build the team kernel with -DGE2E_MARKS -save-temps (GE2E_PROF(i) becomes an assembly comment "; PHASEMARK i", no

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development aid: per-batch / per-row parity of one implementation on a test-style problem, run twice.
 Usage (GPU box): python tools/probe_impl.py impl B N M D [variant] [kind] [w] [b]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where the host time of one GE2ELoss.forward + backward() goes (cProfile over many steps, B = 1).
 usage (GPU box): python tools/profile_module_step.py [N M D]"""
 import cProfile

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: where does a fused-kernel workgroup spend its cycles?
 
 Builds a SEPARATE library (libge2e_hip_prof.so, -DGE2E_PROFILE) whose kernels stamp

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Write one record of profiles/traffic.json from a run_profiles.sh output dir.
 usage: record_traffic.py <prof_dir> <config> <impl> <batches_per_launch> <source-label>
 

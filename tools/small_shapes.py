@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Interleaved timing of the one-wave-per-batch kernel against the workgroup-per-batch kernel on the reference's own
 shapes (a few dozen rows), B = 1 and 4096, C ABI with reused buffers.  Usage (GPU box): python tools/small_shapes.py"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Soak: 300 launches per shape through AUTO, outputs NaN-poisoned before each, every launch bitwise equal to the first and
 the first checked against the fp64 oracle.  Usage (GPU box): python tools/soak_determinism.py"""
 import sys, numpy as np, torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condense rocprofv3 output dirs (kernel trace + FETCH_SIZE / WRITE_SIZE passes) into one
 text summary for profiles/.  usage: summarize_rocprof.py <prof_dir> <out.txt> [label]
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A few GE2ELoss.forward + backward() steps for a rocprofv3 --kernel-trace run (what the device executes per step).
 usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/trace_module_step.py [N M D]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Development aid for rocprofv3 --pmc runs: a few launches of one implementation at cfg2, B=4096, forward only or with
 gradients.  usage: python tools/traffic_probe.py impl {grad|fwd}"""
 import os
