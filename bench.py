@@ -167,8 +167,9 @@ def verify_forward(E, loss, per, N, M, D, variant, w=10.0, b=-5.0):
         ref = orc.closed_form(E[i].cpu().numpy(), w, b, variant=variant, want_grad=False)
         worst["max_loss_rel"] = max(worst["max_loss_rel"], abs(float(loss[i]) - ref["loss"]) / max(abs(ref["loss"]), 1e-30))
         worst["max_per_abs"] = max(worst["max_per_abs"], float(np.abs(per[i].cpu().numpy().astype(np.float64) - ref["per"]).max()))
-    ok = worst["max_loss_rel"] <= 1e-4 and worst["max_per_abs"] <= 1e-3 and all(np.isfinite(v) for v in worst.values())
-    return {"batches": picks, **worst, "tolerance": "loss rtol 1e-4, per-row loss atol 1e-3",
+    # (per-row losses to the 2e-5 tests/test_gpu_team_fwd.py::check_fwd holds them to; the kernels deliver ~2e-6)
+    ok = worst["max_loss_rel"] <= 1e-4 and worst["max_per_abs"] <= 2e-5 and all(np.isfinite(v) for v in worst.values())
+    return {"batches": picks, **worst, "tolerance": "loss rtol 1e-4, per-row loss atol 2e-5",
             "oracle": "oracle.ge2e_oracle.closed_form (fp64)", "ok": bool(ok)}
 
 
@@ -423,7 +424,16 @@ def main():
 
         for _ in range(10):
             module_step()
+        extra["latency_module_eager_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+        # the same two lines of the reference's step through GE2ELoss(hp, graph=True): forward = copy into a static input +
+        # one replay of the captured fused launch, loss.backward() publishes the launch's own dE / dw / db (loss.py)
+        eager_mod, mod = mod, GE2ELoss(HParams(device=dev), variant=variant, impl=args.impl, graph=True)
+        for _ in range(10):
+            module_step()
         extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+        extra["latency_module_b1_route"] = ("GE2ELoss(hp, graph=True): mod(em).backward() served from a HIP graph over static "
+                                            "buffers" if mod._steps else "eager (the shape was not captured)")
+        mod = eager_mod
         # ... and with the autograd node in Python (functional._GE2ELossFunction) instead of libge2e_torch.so's: same launches
         extra["latency_module_autograd_node"] = "c++ (libge2e_torch.so)" if GF._cpp_loss_op() is not None else "python"
         if GF._cpp_loss_op() is not None:

@@ -12,12 +12,12 @@ rank's gradient is the matching slice of its gradient (tests/test_sharded.py: a 
 against the single launch).  (w, b) receive each rank's partial gradient: sum them over the ranks (an all-reduce, e.g. the
 trainer's bucket) for the full one.
 
-Built from the differentiable static helpers in their LOCAL-ROWS form (round 4: ge2e_cos_sim_rows / ge2e_calc_loss_rows and
-their backward kernels, include/ge2e_hip.h): a rank sweeps its own n M rows against the N gathered centroids, the own
-column of local speaker jl being rank n + jl.  (Round 3 embedded the local rows in an (N, M, D) block of zeros because the
-whole-batch helpers want as many centroids as speakers, s3:77-78: G-fold redundant row work; that composition is kept for
-`ops` without the local-rows forms -- the CPU oracle of the gloo test -- and as `padded=True` for comparison.)  The
-data-parallel path the north star prescribes (whole batches per rank, trainer.py) is unaffected.
+Built from the differentiable static helpers in their LOCAL-ROWS form (ge2e_cos_sim_rows / ge2e_calc_loss_rows and their
+backward kernels, include/ge2e_hip.h): a rank sweeps its own n M rows against the N gathered centroids, the own column of
+local speaker jl being rank n + jl.  (The round-3 composition -- the local rows embedded in an (N, M, D) block of zeros so
+that the whole-batch helpers could be used -- lives on only in tests/test_sharded.py, as the CPU oracle's form of the two
+local-rows helpers and as the baseline of a timing comparison.)  The data-parallel path the north star prescribes (whole
+batches per rank, trainer.py) is unaffected.
 """
 from __future__ import annotations
 
@@ -60,17 +60,16 @@ def all_gather_rows(rows: torch.Tensor, group: Optional["dist.ProcessGroup"] = N
 
 def sharded_ge2e_loss(e_local: torch.Tensor, w: torch.Tensor, b: torch.Tensor, rank: int, world: int, *,
                       gather: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, ops=None,
-                      eps: float = 1e-6, variant: str = "softmax", padded: bool = False) -> torch.Tensor:
+                      eps: float = 1e-6, variant: str = "softmax") -> torch.Tensor:
     """This rank's share of the exact N-speaker loss: ``e_local`` (n, M, D) are the rows of speakers
     ``rank * n .. rank * n + n - 1`` of the global batch (N = world * n).  Returns the sum of the per-row losses of the
     LOCAL rows (a scalar that backpropagates into ``e_local``, ``w``, ``b`` and -- through the gather -- into the other
     ranks' rows); the global loss is the sum of the returns over the ranks.
 
     ``gather``: [n, D] -> [N, D] in rank order, differentiable (default: RCCL / gloo all-gather whose backward is a
-    reduce-scatter).  ``ops``: an object with the reference's static helpers ``centroids``, ``cos_sim(e, c, eps=)``,
-    ``calc_loss(sim, eps=, variant=)`` (default: this package's HIP ones, ``functional``, which also have the local-rows
-    forms ``cos_sim_rows`` / ``calc_loss_rows``: n M rows against N centroids instead of an (N, M, D) block of zeros;
-    ``padded=True`` forces the padded composition, for comparison)."""
+    reduce-scatter).  ``ops``: where ``centroids``, ``cos_sim_rows(e, C, first_speaker, eps=)`` and
+    ``calc_loss_rows(sim, first_speaker, eps=, variant=)`` come from (default: this package's HIP ones, ``functional``; the
+    multi-process CPU test plugs the oracle's in -- what it tests is the collective orchestration)."""
     if ops is None:
         from . import functional as ops
     if gather is None:
@@ -81,19 +80,9 @@ def sharded_ge2e_loss(e_local: torch.Tensor, w: torch.Tensor, b: torch.Tensor, r
     C = gather(c_local)                                           # (N, D): everybody's centroids
     if C.shape[0] != N:
         raise RuntimeError(f"gather returned {C.shape[0]} centroids for {N} speakers")
-    if not padded and hasattr(ops, "cos_sim_rows") and hasattr(ops, "calc_loss_rows"):
-        # local-rows kernels (round 4): n M rows against N centroids, own column rank n + jl -- no padding, no G-fold
-        # redundant row work, and the gradient w.r.t. C is this shard's partial one (the gather's backward sums the shards)
-        cos = ops.cos_sim_rows(e_local, C, rank * n, eps=eps)         # (n, M, N)
-        sim = w * cos + b                                             # s3:27
-        loss, _ = ops.calc_loss_rows(sim, rank * n, eps=eps, variant=variant)
-        return loss
-    # compatibility composition for `ops` that only have the reference's whole-batch helpers (the CPU oracle in the gloo
-    # test): the local rows in their global place; the other speakers' rows are zeros (cosine 0, loss masked out below)
-    pad_before = e_local.new_zeros(rank * n, M, D)
-    pad_after = e_local.new_zeros(N - (rank + 1) * n, M, D)
-    e_pad = torch.cat([pad_before, e_local, pad_after], dim=0).contiguous()
-    cos = ops.cos_sim(e_pad, C, eps=eps)                          # (N, M, N); own column: leave-one-out centroid
+    # n M rows against N centroids, own column rank n + jl; the gradient w.r.t. C is this shard's partial one (the gather's
+    # backward sums the shards)
+    cos = ops.cos_sim_rows(e_local, C, rank * n, eps=eps)         # (n, M, N)
     sim = w * cos + b                                             # s3:27
-    _, per = ops.calc_loss(sim, eps=eps, variant=variant)         # (N, M)
-    return per[rank * n:(rank + 1) * n].sum()
+    loss, _ = ops.calc_loss_rows(sim, rank * n, eps=eps, variant=variant)
+    return loss

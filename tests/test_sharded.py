@@ -34,6 +34,33 @@ class OracleOps:
         per = orc._softmax_rows(sim, eps) if variant == "softmax" else orc._contrast_rows(sim)
         return per.sum(), per
 
+    # The local-rows forms sharded_ge2e_loss asks for, composed from the whole-batch helpers above (which want as many
+    # centroids as speakers, s3:77-78): the n local speakers in their global place in an (N, M, .) block of zeros, the
+    # other speakers' rows masked out afterwards.  (Round 3's product composition; G-fold redundant row work.)
+    @staticmethod
+    def cos_sim_rows(e_local, C, first, eps=orc.SMALL_ERR):
+        n, M, D = e_local.shape
+        N = C.shape[0]
+        e_pad = torch.cat([e_local.new_zeros(first, M, D), e_local, e_local.new_zeros(N - first - n, M, D)], dim=0)
+        return OracleOps.cos_sim(e_pad, C, eps)[first:first + n]
+
+    @staticmethod
+    def calc_loss_rows(sim_rows, first, eps=orc.SMALL_ERR, variant="softmax"):
+        n, M, N = sim_rows.shape
+        s_pad = torch.cat([sim_rows.new_zeros(first, M, N), sim_rows, sim_rows.new_zeros(N - first - n, M, N)], dim=0)
+        per = OracleOps.calc_loss(s_pad, eps, variant)[1][first:first + n]
+        return per.sum(), per
+
+
+def padded_sharded_loss(GF, e_local, w, b, rank, world, C, eps=1e-6, variant="softmax"):
+    """Round 3's composition on the HIP helpers (timing baseline of test_gpu_local_rows_beat_the_padded_composition)."""
+    n, M, D = e_local.shape
+    N = n * world
+    e_pad = torch.cat([e_local.new_zeros(rank * n, M, D), e_local, e_local.new_zeros(N - (rank + 1) * n, M, D)], dim=0).contiguous()
+    sim = w * GF.cos_sim(e_pad, C, eps=eps) + b
+    _, per = GF.calc_loss(sim, eps=eps, variant=variant)
+    return per[rank * n:(rank + 1) * n].sum()
+
 
 def _global_batch(N=6, M=4, D=16, seed=5):
     return torch.from_numpy(orc.synth_embeddings((N, M, D), "unit", seed=seed)).float()
@@ -240,7 +267,8 @@ def test_gpu_local_rows_beat_the_padded_composition():
             w = torch.tensor(10.0, device=dev, requires_grad=True)
             b = torch.tensor(-5.0, device=dev, requires_grad=True)
             cc = cents.clone().requires_grad_(True)
-            loss = sharded.sharded_ge2e_loss(a, w, b, 3, world, gather=lambda c_: cc, padded=padded)
+            loss = (padded_sharded_loss(GF, a, w, b, 3, world, cc) if padded
+                    else sharded.sharded_ge2e_loss(a, w, b, 3, world, gather=lambda c_: cc))
             loss.backward()
             return loss.detach(), a.grad, cc.grad, w.grad
         for _ in range(3):

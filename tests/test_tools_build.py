@@ -19,3 +19,19 @@ def test_micro_benchmark_compiles_for_gfx950(src, tmp_path):
     out = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", inc, "-c", "-o", str(tmp_path / "x.o"), src],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_every_profile_cited_by_traffic_json_exists():
+    """profiles/traffic.json feeds `roofline.traffic` of the bench line and cites the rocprofv3 summary each record came
+    from: a citation that points at no committed file is a dangling reference in a driver record."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "traffic.json")) as f:
+        table = json.load(f)
+    assert table
+    for key, rec in table.items():
+        src = rec.get("source", "")
+        path = src.split(" ", 1)[0]
+        assert path.startswith("profiles/") and path.endswith(".txt"), (key, src)
+        assert os.path.isfile(os.path.join(root, path)), f"{key}: {path} is cited but not committed"

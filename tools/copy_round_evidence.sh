@@ -1,6 +1,6 @@
 #!/bin/bash
 # After tools/run_round_evidence.sh <label> came back: copy what is judged from gpurun_out/ into profiles/.
-label=${1:-r05}
+label=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 cp gpurun_out/traffic.json profiles/traffic.json
 for c in cfg1:wave cfg2:team cfg3:team cfg4:tiled cfg5:tiled; do
@@ -9,8 +9,8 @@ for c in cfg1:wave cfg2:team cfg3:team cfg4:tiled cfg5:tiled; do
   cp gpurun_out/prof_${label}_${cfg}_auto/kernel_stats.csv profiles/${label}_${cfg}_${im}_kernel_stats.csv
 done
 f=gpurun_out/${label}_fwd
-cp $f/rocprof_summary.txt profiles/${label}_cfg2_fwd_team_rocprof.txt
-cp $f/kernel_stats.csv profiles/${label}_cfg2_fwd_team_kernel_stats.csv
+cp $f/rocprof_summary.txt profiles/${label}_cfg2_team_fwd_rocprof.txt
+cp $f/kernel_stats.csv profiles/${label}_cfg2_team_fwd_kernel_stats.csv
 cp $f/sq_counters.txt profiles/${label}_cfg2_fwd_sq_counters.txt
 cp $f/phase_stamps_wave0.txt profiles/${label}_cfg2_fwd_phase_stamps.txt
 cp $f/phase_stamps_wave4.txt profiles/${label}_cfg2_fwd_phase_stamps_wave4.txt
