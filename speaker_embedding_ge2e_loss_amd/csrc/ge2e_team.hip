@@ -299,8 +299,8 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L,
                 // d4 + 3 of slot kslot: half a fragment.
                 const unsigned blk = (unsigned)(kslot >> 4) * (4u * NCH) + (unsigned)(lv_ >> 3);      // hi block of its K-step
                 const unsigned vh = dact ? blk * 1024u + (unsigned)(((lv_ >> 1) & 3) * 16 + (kslot & 15)) * 16u + (unsigned)(lv_ & 1) * 8u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + XO.chr[buf], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsX, vh + XO.chr[buf], 0, GE2E_T2_XC_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsX, vh + XO.chr[buf] + 2048u * NCH, 0, GE2E_T2_XC_AUX);
             }
             if (dact && want_grad) {   // one 8-byte write per image: a row of the stage per wave (the k-group form is gE's operand)
                 *reinterpret_cast<h4*>(STG + wid * SP + d4) = hi;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void ge2e_team_kernel(Problem p, TeamKWs L,
             const _Float16* p0 = STG + (8 * hl + (l16 >> 2)) * SP + (d - l16) + 4 * (l16 & 3);
             const h4 a = tr_read4(p0), b2 = tr_read4(p0 + 4 * SP);
             const h8 v = __builtin_shufflevector(a, b2, 0, 1, 2, 3, 4, 5, 6, 7);
-            bstore4(rsX, XO.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, __builtin_bit_cast(float4, v));
+            bstore4<GE2E_T2_XC_AUX>(rsX, XO.cht[buf] + (unsigned)id.member * (2u * D * 16u) + (unsigned)tid * 16u, __builtin_bit_cast(float4, v));
         }
         // ---- one drain + barrier publishes prev's partial gradients (hand-off 2) and cur's centroid (hand-off 1)
         GE2E_PROF_SUB(17);
@@ -898,7 +898,7 @@ _Pragma("unroll")                                                               
 #pragma unroll
                                     for (int t = 0; t < 4; ++t)
                                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gc[b][4 * g + t]), rsX, ob,
-                                                                              (unsigned)((t + 8 * g) * D + 32 * b) * 4u, 0);
+                                                                              (unsigned)((t + 8 * g) * D + 32 * b) * 4u, GE2E_T2_GC_AUX);
                             }
                         }
                         if (kh == (id.member >> 2)) {

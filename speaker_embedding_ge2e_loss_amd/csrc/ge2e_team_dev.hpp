@@ -29,6 +29,15 @@ constexpr int AUX_NT = 2;
 // column tile i of this wave in GE / dE.  Two tiles per wave (D > 128): ADJACENT tiles, so that after the half-row
 // exchange at the end of GE a lane pair-of-tiles covers whole 128-byte lines of dE (see T2_PAIR_LINES)
 #define T2_DT(i) (NTI == 2 ? 2 * wid + (i) : wid + 8 * (i))
+// ... of the EXCHANGE stores (published centroids in both forms; partial centroid gradients).  Every store's bytes leave the
+// XCD's L2 for the fabric whatever the pressure (tools/ubench/l2_rewrite.hip: 64 rewrites of a 2-MiB-per-XCD set = 64 copies
+// of WRITE_SIZE with plain or sc1 stores, 40 with nt -- the L2 merges some nt rewrites); the readers take them from L2 (sc1 loads)
+#ifndef GE2E_T2_XC_AUX
+#define GE2E_T2_XC_AUX 0
+#endif
+#ifndef GE2E_T2_GC_AUX
+#define GE2E_T2_GC_AUX 0
+#endif
 #ifndef GE2E_T2_E_AUX
 #define GE2E_T2_E_AUX 2       // ... and of the E loads
 #endif

@@ -180,6 +180,52 @@ def test_gpu_shards_equal_the_single_launch(world, variant):
 
 
 @pytest.mark.gpu
+def test_gpu_eight_shards_end_to_end_time():
+    """N = 256, M = 10, D = 256 (cfg4's batch) as ONE launch against the same loss cut into 8 speaker shards, forward +
+    backward, end to end on one device (the shards one after the other: what eight ranks would each do once, plus the
+    gather's cat and its backward).  A record, not a gate beyond sanity: printed, and quoted in DESIGN.md section 6."""
+    import time
+    from speaker_embedding_ge2e_loss_amd import functional as GF
+
+    N, M, D, world = 256, 10, 256, 8
+    n = N // world
+    dev = torch.device("cuda:0")
+    e = torch.from_numpy(orc.synth_embeddings((N, M, D), "unit", seed=78)).float().to(dev)
+
+    def single():
+        a = e.clone().requires_grad_(True)
+        w = torch.tensor(10.0, device=dev, requires_grad=True)
+        b = torch.tensor(-5.0, device=dev, requires_grad=True)
+        GF.ge2e_loss(a, w, b).backward()
+        return a.grad
+
+    def shards8():
+        sh = [e[k * n:(k + 1) * n].clone().requires_grad_(True) for k in range(world)]
+        w = torch.tensor(10.0, device=dev, requires_grad=True)
+        b = torch.tensor(-5.0, device=dev, requires_grad=True)
+        cents = [GF.centroids(s_) for s_ in sh]
+        tot = sum(sharded.sharded_ge2e_loss(sh[k], w, b, k, world, gather=lambda c: torch.cat(cents, 0)) for k in range(world))
+        tot.backward()
+        return torch.cat([s_.grad for s_ in sh], 0)
+
+    t = {}
+    for name, fn in (("single launch", single), ("eight shards", shards8)):
+        for _ in range(3):
+            g = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            g = fn()
+        torch.cuda.synchronize()
+        t[name] = ((time.perf_counter() - t0) / 10, g)
+    rel = float((t["eight shards"][1] - t["single launch"][1]).norm() / t["single launch"][1].norm())
+    print(f"N=256 M=10 D=256 forward + backward, one device: single launch {t['single launch'][0] * 1e6:.0f} us, "
+          f"8 shards one after the other {t['eight shards'][0] * 1e6:.0f} us ({t['eight shards'][0] / world * 1e6:.0f} us per shard); "
+          f"dE rel-Frobenius difference {rel:.1e}")
+    assert rel <= 2e-5
+
+
+@pytest.mark.gpu
 def test_gpu_single_rank_nccl_group():
     """The default gather (all-gather forward, reduce-scatter backward) over RCCL with one rank: world 1 is the plain loss."""
     from speaker_embedding_ge2e_loss_amd import functional as GF

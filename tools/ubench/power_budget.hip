@@ -97,6 +97,31 @@ __global__ __launch_bounds__(512) void k_mfma(float* sink, int iters) {
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678f) sink[0] = s;
 }
+// the same 16 MFMAs per trip on RANDOM operands that change from instruction to instruction (eight A and eight B fragments of
+// hashed bits in [-1, 1), as unit-vector halves are): the loop above feeds ONE smooth pair again and again, and the matrix
+// pipe's energy depends on how many operand bits toggle (MI355X_MICROARCH.md, DVFS give-back item 1: zeros ran +19 %)
+__global__ __launch_bounds__(512) void k_mfma_rand(float* sink, int iters) {
+    h8 a[8], b[8];
+    unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            st = st * 1664525u + 1013904223u; a[k][i] = (_Float16)(((int)(st >> 8) & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+            st = st * 1664525u + 1013904223u; b[k][i] = (_Float16)(((int)(st >> 8) & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+        }
+    f32x4 acc[4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(4 * r + i) & 7], b[(4 * r + i + 3) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) sink[0] = s;
+}
 // 16 ds_read_b128 per trip (conflict-free)
 __global__ __launch_bounds__(512) void k_lds(float* sink, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,6 +241,80 @@ __global__ __launch_bounds__(512) void k_valu_dpp(float* sink, int iters) {
     if (s == 12345.678f) sink[0] = s;
 }
 
+// ---- round 6: the activities the round-5 ledger left out (62-96 uJ of 465 per batch were unattributed) --------------------
+// scalar ALU: 32 dependent-free s_add / s_mul / s_and / s_lshl per trip (the team kernel issues 435 scalar instructions per
+// wave and batch: address arithmetic, buffer resources, loop control)
+__global__ __launch_bounds__(512) void k_salu(float* sink, int iters, int a) {
+    int x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3, x4 = a + 4, x5 = a + 5, x6 = a + 6, x7 = a + 7;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("s_add_u32 %0, %0, %1" : "+s"(x0) : "s"(a) : "scc");
+            asm volatile("s_mul_i32 %0, %0, %1" : "+s"(x1) : "s"(a) : "scc");
+            asm volatile("s_and_b32 %0, %0, %1" : "+s"(x2) : "s"(a) : "scc");
+            asm volatile("s_lshl_b32 %0, %0, 1" : "+s"(x3) : : "scc");
+            asm volatile("s_add_u32 %0, %0, %1" : "+s"(x4) : "s"(a) : "scc");
+            asm volatile("s_mul_i32 %0, %0, %1" : "+s"(x5) : "s"(a) : "scc");
+            asm volatile("s_xor_b32 %0, %0, %1" : "+s"(x6) : "s"(a) : "scc");
+            asm volatile("s_sub_u32 %0, %0, %1" : "+s"(x7) : "s"(a) : "scc");
+        }
+    }
+    if (x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 == 123456789) sink[0] = 1.f;
+}
+// eight waves per CU standing at s_waitcnt behind ONE dependent L2 round trip each (a pointer chase through a 2-MiB span:
+// every load's address comes from the previous load): what a wave costs while it waits for memory, and what the round
+// trips themselves cost at this (low) rate
+__global__ __launch_bounds__(512) void k_wait_l2(const unsigned* chain, float* sink, int iters) {
+    unsigned idx = (blockIdx.x * 8u + (threadIdx.x >> 6)) * 4099u & 0x7FFFFu;        // 2 MiB of dwords
+    for (int it = 0; it < iters; ++it) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(idx * 4u), "s"(chain) : "memory");
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)v) & 0x7FFFFu;
+    }
+    if (idx == 0x7FFFFFFFu) sink[0] = 1.f;
+}
+// the hand-off wait of the team kernels: ONE lane per workgroup polls a word in L2 (sc1 load, s_sleep 2 between polls) while
+// the other seven waves stand at the workgroup barrier behind it
+__global__ __launch_bounds__(512) void k_poll(const unsigned* word, float* sink, int polls) {
+    if (threadIdx.x == 0) {
+        unsigned seen = 0;
+        for (int k = 0; k < polls; ++k) {
+            seen += __hip_atomic_load(word + 32 * (blockIdx.x & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (seen == 0x7FFFFFFFu) sink[0] = 1.f;
+    }
+    __syncthreads();
+}
+// workgroup barriers back to back: all eight waves arrive, leave, arrive ... (the training kernel has ten per batch)
+__global__ __launch_bounds__(512) void k_barrier_rate(float* sink, int iters) {
+    for (int it = 0; it < iters; ++it) __syncthreads();
+    if (sink == nullptr) return;
+}
+// the streams above read what hipMemset left (zeros) and store four small constants: real embeddings toggle every data line.
+// k_fill writes hashed bits so that the read activities can be repeated on random data
+__global__ __launch_bounds__(512) void k_fill(unsigned* buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (size_t)gridDim.x * 512) {
+        unsigned x = (unsigned)i * 2654435761u + (unsigned)(i >> 32) * 40503u;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        buf[i] = x;
+    }
+}
+__global__ __launch_bounds__(512) void k_stream_store_rand(float* buf, size_t span_bytes, int iters) {
+    const size_t nchunks = span_bytes >> 16;
+    const unsigned lane_off = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 8192;
+    unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 7u;
+    for (int it = 0; it < iters; ++it) {
+        const size_t c = ((size_t)blockIdx.x + (size_t)it * gridDim.x) % nchunks;
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(buf) + (c << 16), 0, 65536, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x = x * 1664525u + 1013904223u;
+            const u32x4 val = {x, x * 2246822519u, x ^ 0x9E3779B9u, x * 3266489917u};
+            __builtin_amdgcn_raw_buffer_store_b128(val, r2, lane_off + 1024u * i, 0, 2);
+        }
+    }
+}
 // ---- host: run an activity for `secs`, sample rocm-smi meanwhile -----------------------------------------------------------
 static bool smi(double& watts, double& mhz) {
     FILE* f = popen("/opt/rocm/bin/rocm-smi --showclocks --showpower -d 0 2>/dev/null", "r");
@@ -289,6 +388,18 @@ int main(int argc, char** argv) {
       report("7 of 8 waves per CU parked at s_barrier", r, waves, "wave-launches", 1.0, "J per wave-launch"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu, dim3(cus), dim3(512), 0, 0, sink, IT, 1.0001f); });
       report("v_fma_f32, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_salu, dim3(cus), dim3(512), 0, 0, sink, IT, 3); });
+      report("scalar ALU (s_add / s_mul / s_and ...), 8 waves per CU", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_barrier_rate, dim3(cus), dim3(512), 0, 0, sink, IT * 4); });
+      report("s_barrier back to back, 8 waves per CU", r, (double)cus * IT * 4.0, "barriers", 1e9, "nJ per workgroup barrier"); }
+    { unsigned* chain; CK(hipMalloc(&chain, 1u << 21));
+      std::vector<unsigned> hc(1u << 19); for (unsigned i = 0; i < hc.size(); ++i) hc[i] = (i * 2654435761u + 12345u) & 0x7FFFFu;
+      CK(hipMemcpy(chain, hc.data(), 1u << 21, hipMemcpyHostToDevice));
+      { auto r = run(secs, [&] { hipLaunchKernelGGL(k_wait_l2, dim3(cus), dim3(512), 0, 0, chain, sink, 4000); });
+        report("8 waves per CU at s_waitcnt, one L2 round trip each", r, waves * 4000.0, "round trips", 1e9, "nJ per wave round trip"); }
+      { auto r = run(secs, [&] { hipLaunchKernelGGL(k_poll, dim3(cus), dim3(512), 0, 0, chain, sink, 4000); });
+        report("one lane per CU polls L2 (sc1 + s_sleep 2), 7 waves at the barrier", r, (double)cus * 4000.0, "polls", 1e9, "nJ per poll (incl. the waiting waves)"); }
+      CK(hipFree(chain)); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu_cvt, dim3(cus), dim3(512), 0, 0, sink, IT, 1.0001f); });
       report("v_cvt_pk_f16_f32, 2 waves per SIMD", r, waves * IT * 32.0, "wave-instr", 1e9, "nJ per wave-instr"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_valu_mix, dim3(cus), dim3(512), 0, 0, sink, IT, 1.0001f); });
@@ -301,6 +412,8 @@ int main(int argc, char** argv) {
       report("mfma 16x16x32 f16, 1 wave per SIMD", r, cus * 4.0 * (IT / 2) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma<8>, dim3(cus), dim3(512), 0, 0, sink, IT / 4); });
       report("mfma 16x16x32 f16, 2 waves per SIMD", r, cus * 8.0 * (IT / 4) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma_rand, dim3(cus), dim3(512), 0, 0, sink, IT / 4); });
+      report("mfma 16x16x32 f16, RANDOM operands, 2 waves/SIMD", r, cus * 8.0 * (IT / 4) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma32, dim3(cus), dim3(512), 0, 0, sink, IT / 8); });
       report("mfma 32x32x16 f16, 2 waves per SIMD", r, cus * 8.0 * (IT / 8) * 8.0, "MFMA", 1e9, "nJ per MFMA (32.8 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_lds, dim3(cus), dim3(512), 65536, 0, sink, IT / 2); });
@@ -317,5 +430,22 @@ int main(int argc, char** argv) {
       report("sequential 64-KB chunks, nt loads (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_stream<1>, dim3(cus), dim3(512), 0, 0, buf, big, sink, 400); });
       report("sequential 64-KB chunks, nt stores (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    // the HBM streams again on RANDOM data (the passes above moved zeros / constants)
+    hipLaunchKernelGGL(k_fill, dim3(cus * 8), dim3(512), 0, 0, reinterpret_cast<unsigned*>(buf), big / 4);
+    CK(hipDeviceSynchronize());
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_stream<0>, dim3(cus), dim3(512), 0, 0, buf, big, sink, 400); });
+      report("RANDOM data: sequential 64-KB chunks, nt loads (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_stream_store_rand, dim3(cus), dim3(512), 0, 0, buf, big, 400); });
+      report("RANDOM data: sequential 64-KB chunks, nt stores (HBM)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    { const size_t span = (size_t)1 << 21;
+      auto r = run(secs, [&] { hipLaunchKernelGGL(k_read<0>, dim3(cus), dim3(512), 0, 0, buf, span, sink, 400); });
+      report("RANDOM data: 16-B loads, 2 MiB span (L2 hits)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
+    // "hot idle": the resident-waves point again, right behind ten seconds of matrix work at the power limit -- leakage at the
+    // loaded die temperature is part of what a kernel at the cap pays per second, and the first point above was taken cold
+    { run(10.0, [&] { hipLaunchKernelGGL(k_mfma<8>, dim3(cus), dim3(512), 0, 0, sink, IT / 4); });
+      auto r = run(2.0, [&] { hipLaunchKernelGGL(k_sleep, dim3(cus), dim3(512), 0, 0, sink, 4000); });
+      report("HOT: 8 waves per CU in s_sleep, behind 10 s of MFMA", r, waves, "wave-launches", 1.0, "J per wave-launch");
+      auto r2 = run(2.0, [&] { hipLaunchKernelGGL(k_barrier, dim3(cus), dim3(512), 0, 0, sink, 100); });
+      report("HOT: 7 of 8 waves parked at s_barrier (2 s later)", r2, waves, "wave-launches", 1.0, "J per wave-launch"); }
     return 0;
 }
