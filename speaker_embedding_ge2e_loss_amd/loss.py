@@ -43,7 +43,7 @@ class _GraphedLossFunction(torch.autograd.Function):
     def forward(ctx, embeddings, w, b, step):
         step.run(embeddings)
         ctx.step, ctx.serial = step, step.serial
-        return step.loss1[0]                     # a fresh 0-dim view of the static loss
+        return step.loss1[0].clone()             # (a copy: callers collect the losses of many steps, e.g. DPTrainer.fit)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -82,8 +82,8 @@ class GE2ELoss(nn.Module):
         served from a HIP graph over static buffers once the same (N, M, D) has come twice in a row: ``forward`` copies the
         embeddings in and replays the fused launch, and a plain ``loss.backward()`` publishes the launch's own dE / dw / db
         as the gradients without going through the autograd engine (same bits: the engine would multiply them by 1.0).
-        The returned loss and the ``.grad`` tensors it sets are STATIC -- overwritten by the next forward (a ``.grad`` that
-        is still attached then is cloned first, so accumulating over several steps stays correct).  Anything else -- another
+        The ``.grad`` tensors the shortcut sets are STATIC -- overwritten by the next forward (a ``.grad`` that is still attached
+        then is cloned first, so accumulating over several steps stays correct); the returned loss is a copy.  Anything else -- another
         shape, a (B, N, M, D) stack, no-grad mode, a stream that is capturing, hooks on the tensors, ``backward`` with
         arguments -- takes the eager node."""
         super().__init__()

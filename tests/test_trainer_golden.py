@@ -132,6 +132,21 @@ def test_mixed_dtype_parameters_are_refused():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FIXTURES)
+def test_trainer_with_the_graph_route_loss_on_gpu(name):
+    """GE2ELoss(hp, graph=True) inside the trainer: the embeddings come out of the encoder (not a leaf), the parameters'
+    gradients are views of the flat bucket (the shortcut adds into them), the test loss runs under no_grad (eager node)."""
+    from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+    dev = torch.device("cuda:0")
+    z, c = load(name)
+    loss = GE2ELoss(HParams(device=dev), graph=True)
+    tr = DPTrainer(encoder_from(z, c, dev), loss, lr=c["lr"], seed=c["seed"])
+    losses, test = run_trajectory(z, c, tr, dev)
+    check(z, c, tr, losses, test, rtol=1e-4)
+    assert len(loss._steps) == 1                       # captured on the second step, replayed from then on
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIXTURES)
 @pytest.mark.parametrize("fused_tail", [False, True])
 def test_trainer_with_hip_loss_on_gpu(name, fused_tail):
     """The same trajectories with the product: encoder on the device (MIOpen/rocBLAS LSTM), the HIP

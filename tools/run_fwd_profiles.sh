@@ -5,7 +5,7 @@
 # the queue full.  usage: bash tools/run_fwd_profiles.sh <round-label> [impl]
 # Everything lands under gpurun_out/<label>_fwd/ (copy what should be judged into profiles/).
 set +e
-label=${1:-r05}
+label=${1:-r06}
 impl=${2:-auto}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/${label}_fwd

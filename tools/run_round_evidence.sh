@@ -3,15 +3,17 @@
 # rocprofv3 kernel stats + HBM-traffic PMC passes of each, the forward-only evidence set, SQ counters and phase stamps of the
 # metric kernel, clock / power, the GPU test log.  usage: bash tools/run_round_evidence.sh r05
 # Progress goes to gpurun_out/<label>_evidence.log (a line per step: the call must not look hung).
-label=${1:-r05}
+label=${1:-r06}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 log=gpurun_out/${label}_evidence.log
 mkdir -p gpurun_out
 echo "start $(date)" > $log
-bash tools/run_round_benches.sh $label >> $log 2>&1; echo "benches done $(date)" >> $log
+# the PMC passes first: they write profiles/traffic.json for THIS tree's source hash, which the bench lines below then carry
+# as roofline.traffic (same call, same box: the kernel averages of the profiles and the lines' ms_per_step belong together)
 bash tools/run_profiles.sh $label "cfg2:auto cfg1:auto cfg3:auto cfg4:auto cfg5:auto" >> $log 2>&1; echo "profiles done $(date)" >> $log
 bash tools/run_fwd_profiles.sh $label auto >> $log 2>&1; echo "fwd profiles done $(date)" >> $log
+bash tools/run_round_benches.sh $label >> $log 2>&1; echo "benches done $(date)" >> $log
 cd $root
 CFG=cfg2 IMPLS="team" bash tools/run_sq_counters.sh > gpurun_out/${label}_sq_counters_cfg2_team.txt 2>&1; echo "sq done $(date)" >> $log
 cd $root
