@@ -7,7 +7,7 @@
 // wave keeps the MFMA fragments it needs in registers, loaded straight from the team's L2-resident exchange area
 // (row-major for X = ET . CH^T, and as 16-byte k-groups per column for gE = G . CH).
 //
-// One iteration starts batch n ("cur") and finishes batch n - 1 ("prev"); phases in program order (DESIGN.md 3a):
+// One iteration starts batch n ("cur") and finishes batch n - 1 ("prev"); phases in program order (DESIGN.md 3.2):
 //   A1   wave s = speaker slot s: sum of its M rows (prefetched registers) -> unit centroid -> published in both forms;
 //        drain, barrier, signal: prev's partial gradients (hand-off 2) and cur's centroids (hand-off 1)
 //   A2   the wave's rows -> |e|, e-hat -> ET images (the hand-off travels meanwhile)

@@ -1,6 +1,6 @@
 // Socket power of ONE activity at a time on all CUs (tools only, not part of the product): what a wave-instruction, an MFMA,
 // an LDS byte, an L2 byte and an HBM byte cost in joules on this MI355X, for the energy budget of the team kernels
-// (DESIGN.md "what bounds cfg2").  Each activity runs back to back for a few seconds while the host samples rocm-smi; the
+// (DESIGN.md 3.2).  Each activity runs back to back for a few seconds while the host samples rocm-smi; the
 // program prints rate, mean socket power over the steady part and (power - idle) / rate.
 //   hipcc -O3 --offload-arch=gfx950 -o power_budget power_budget.hip && ./power_budget [seconds per activity]
 #include <hip/hip_runtime.h>
