@@ -23,7 +23,7 @@
 //
 // Shapes: D % 8 == 0 (rows of the fp16 planes 16-byte aligned; ragged K-steps and tiles are the cores' business), D <= 1024, N <= 1024 (row values of k_rows live in registers), any M >= 2.
 // Same algebra and same split arithmetic as ge2e_fused_split.hip.  Config 5 is bound by the contractions, config
-// 4 by the bytes the pipeline moves (DESIGN section 8).
+// 4 by the bytes the pipeline moves (DESIGN.md 3.5).
 #include "ge2e_common.hpp"
 #include "ge2e_split_gemm.hpp"
 #include "ge2e_tiled.hpp"
