@@ -114,6 +114,14 @@ class GE2ELoss(nn.Module):
 
     _MAX_STEPS = 4
 
+    def __getstate__(self):
+        # captured graphs and their static buffers belong to THIS object: a copy (copy.deepcopy, pickling, DataParallel's
+        # replicate) starts without them and captures its own
+        state = self.__dict__.copy()
+        state["_steps"] = {}
+        state["_last_shape"] = None
+        return state
+
     def _forward_graphed(self, e):
         if (e.dim() != 3 or not e.is_cuda or e.dtype != torch.float32 or not e.is_contiguous() or e.device != self.w.device
                 or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing()):

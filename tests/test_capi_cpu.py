@@ -126,3 +126,18 @@ def test_cpp_autograd_library_builds_loads_and_refuses_cpu_tensors():
     assert op is not None
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         op(torch.randn(4, 5, 8), torch.tensor(10.0), torch.tensor(-5.0), 1e-6, 1e-8, 0, 0)
+
+
+def test_graph_route_module_copies_start_without_captured_graphs():
+    """GE2ELoss(hp, graph=True) keeps captured HIP graphs and their static buffers: a copy (deepcopy, pickle) must not drag
+    them along (a CUDAGraph cannot be copied) -- it starts empty and captures its own.  Parameters and options copy."""
+    import copy
+    import pickle
+    from speaker_embedding_ge2e_loss_amd import GE2ELoss, HParams
+    m = GE2ELoss(HParams(device="cpu"), variant="contrast", graph=True)
+    m._steps["k"] = object()          # stands in for a captured step
+    m._last_shape = ("k",)
+    for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert c._steps == {} and c._last_shape is None
+        assert c.graph and c.variant == "contrast" and list(c.state_dict()) == ["w", "b"]
+    assert "k" in m._steps
