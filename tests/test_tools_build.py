@@ -35,3 +35,19 @@ def test_every_profile_cited_by_traffic_json_exists():
         path = src.split(" ", 1)[0]
         assert path.startswith("profiles/") and path.endswith(".txt"), (key, src)
         assert os.path.isfile(os.path.join(root, path)), f"{key}: {path} is cited but not committed"
+
+
+def test_every_profile_file_cited_in_the_docs_exists():
+    """DESIGN.md / README.md / INTEGRATION.md argue with files under profiles/: a citation of a file that is not committed
+    is an argument nobody can check."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        with open(os.path.join(root, doc)) as f:
+            text = f.read()
+        for name in sorted(set(re.findall(r"profiles/([A-Za-z0-9_\-\.]+\.(?:txt|json|csv))", text))):
+            if not os.path.isfile(os.path.join(root, "profiles", name)):
+                missing.append((doc, name))
+    assert not missing, missing
