@@ -123,9 +123,13 @@ __global__ __launch_bounds__(512) void k_mfma_rand(float* sink, int iters) {
     if (s == 12345.678f) sink[0] = s;
 }
 // 16 ds_read_b128 per trip (conflict-free)
+template <bool RANDOM>
 __global__ __launch_bounds__(512) void k_lds(float* sink, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<float*>(smem)[i] = (float)i;
+    for (int i = threadIdx.x; i < 16384; i += 512) {
+        unsigned x = (unsigned)i * 2654435761u + blockIdx.x * 40503u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        reinterpret_cast<float*>(smem)[i] = RANDOM ? __uint_as_float((x & 0x007fffffu) | 0x3f000000u) : (float)i;   // random mantissas in [0.5, 1)
+    }
     __syncthreads();
     const char* base = smem + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;
     f32x4 acc = {};
@@ -368,7 +372,8 @@ int main(int argc, char** argv) {
     float* buf;
     CK(hipMalloc(&buf, big));
     CK(hipMemset(buf, 0, big));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     const double waves = (double)cus * 8;
     printf("MI355X, %d CUs, %.1f s per activity; socket power from rocm-smi (mean of the steady samples)\n", cus, secs);
     std::this_thread::sleep_for(std::chrono::seconds(1));
@@ -416,8 +421,10 @@ int main(int argc, char** argv) {
       report("mfma 16x16x32 f16, RANDOM operands, 2 waves/SIMD", r, cus * 8.0 * (IT / 4) * 16.0, "MFMA", 1e9, "nJ per MFMA (16.4 kFLOP)"); }
     { auto r = run(secs, [&] { hipLaunchKernelGGL(k_mfma32, dim3(cus), dim3(512), 0, 0, sink, IT / 8); });
       report("mfma 32x32x16 f16, 2 waves per SIMD", r, cus * 8.0 * (IT / 8) * 8.0, "MFMA", 1e9, "nJ per MFMA (32.8 kFLOP)"); }
-    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_lds, dim3(cus), dim3(512), 65536, 0, sink, IT / 2); });
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_lds<false>, dim3(cus), dim3(512), 65536, 0, sink, IT / 2); });
       report("ds_read_b128, 2 waves per SIMD", r, waves * (IT / 2) * 16.0 * 1024.0, "B", 1e12, "pJ per LDS byte"); }
+    { auto r = run(secs, [&] { hipLaunchKernelGGL(k_lds<true>, dim3(cus), dim3(512), 65536, 0, sink, IT / 2); });
+      report("ds_read_b128, RANDOM data, 2 waves per SIMD", r, waves * (IT / 2) * 16.0 * 1024.0, "B", 1e12, "pJ per LDS byte"); }
     { const size_t span = (size_t)1 << 21;       // 2 MiB: stays in every XCD's L2
       auto r = run(secs, [&] { hipLaunchKernelGGL(k_read<0>, dim3(cus), dim3(512), 0, 0, buf, span, sink, 400); });
       report("16-B loads, 2 MiB span (L2 hits)", r, waves * 400.0 * 8.0 * 1024.0, "B", 1e12, "pJ per byte"); }
