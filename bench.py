@@ -428,12 +428,18 @@ def main():
         # the same two lines of the reference's step through GE2ELoss(hp, graph=True): forward = copy into a static input +
         # one replay of the captured fused launch, loss.backward() publishes the launch's own dE / dw / db (loss.py)
         eager_mod, mod = mod, GE2ELoss(HParams(device=dev), variant=variant, impl=args.impl, graph=True)
-        for _ in range(10):
-            module_step()
-        extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
-        extra["latency_module_b1_route"] = ("GE2ELoss(hp, graph=True): mod(em).backward() served from a HIP graph over static "
-                                            "buffers" if mod._steps else "eager (the shape was not captured)")
+        try:
+            for _ in range(10):
+                module_step()
+            extra["latency_module_b1_us"] = float(np.median(time_launches(module_step, 100))) * 1e3
+            extra["latency_module_b1_route"] = ("GE2ELoss(hp, graph=True): mod(em).backward() served from a HIP graph over "
+                                                "static buffers" if mod._steps else "eager (the shape was not captured)")
+        except Exception as ex:   # a runtime that cannot capture: the eager figure stands in, and the line says so
+            torch.cuda.synchronize()
+            extra["latency_module_b1_us"] = extra["latency_module_eager_b1_us"]
+            extra["latency_module_b1_route"] = f"eager (graph route failed: {str(ex)[:120]})"
         mod = eager_mod
+        em.grad = None
         # ... and with the autograd node in Python (functional._GE2ELossFunction) instead of libge2e_torch.so's: same launches
         extra["latency_module_autograd_node"] = "c++ (libge2e_torch.so)" if GF._cpp_loss_op() is not None else "python"
         if GF._cpp_loss_op() is not None:
