@@ -34,8 +34,8 @@ constexpr unsigned long long TEAM_HANDOFF_TICKS = 400000ull;   // 4 ms: a hand-o
 // magic word -- and ONE launch does everything (round 5; rounds 2-4 queued a gated one-workgroup-per-batch launch behind
 // every team launch, which redid the call when the abort word was up and cleaned the block either way):
 //   * every workgroup of the team launch ends in team_finish(): it counts itself in `done`, waits until the whole grid has
-//     (all workgroups are resident -- the launch condition), reads the abort word, counts itself in `seen`; the workgroup
-//     that completes `seen` rewrites the block (nobody reads it any more).  With the abort word up -- no team formed, a
+//     (all workgroups are resident -- the launch condition), reads the abort word and counts itself in `done`; the workgroup
+//     that completes the count rewrites the block (nobody reads it any more).  With the abort word up -- no team formed, a
 //     hand-off timed out -- ALL workgroups are still there and redo the call with the one-workgroup-per-batch body
 //     (ge2e_fused_split_body.hpp), batches wg, wg + n, ...: never NaN, never stale outputs, no second launch;
 //   * a block that does not carry the magic -- a fresh allocation, memory another implementation has written over -- holds
@@ -50,18 +50,24 @@ struct TeamCtl {
     unsigned abort_;    unsigned pad1[31];
     unsigned nct;       unsigned pad2[31];              // complete teams (written by workgroup 0, diagnostic)
     unsigned xcd_count[MAX_XCD][32];                    // one line per XCD
-    unsigned done;      unsigned pad3[31];              // workgroups that have finished their batches (team_finish)
-    unsigned magic;     unsigned pad4[31];              // TEAM_MAGIC <=> the rest of the block (and the team flags) is zero
+    unsigned done;      unsigned pad3[31];              // team_finish, ONE word for both counts: low 16 bits = workgroups that have
+                                                        // finished their batches, high 16 bits = those of them that found the abort
+                                                        // word up and stay for the redo (a stayer adds 0x10001: its rank and its
+                                                        // arrival are one atomic, so the add that completes the low half returns
+                                                        // the final number of stayers)
+    unsigned magic;                                     // TEAM_MAGIC <=> the rest of the block (and the team flags) is zero
+    unsigned gen;       unsigned pad4[30];              // != 0: the launch (Problem::launch_seq) whose workgroup 0 wrote this block
+                                                        // after a redo WITHOUT counters; that launch's own late workgroups must
+                                                        // not take the block for a clean one (team_form).  Same 8 bytes as the
+                                                        // magic: written by one store, read by one load
     unsigned fallbacks; unsigned pad5[31];              // diagnostic, survives the clean-up: calls on this workspace whose abort
                                                         // word was up (no team formed, a hand-off timed out, unclean block)
-    unsigned seen;      unsigned pad6[31];              // workgroups that have found the abort word up at the end (team_finish): ranks
     unsigned go;        unsigned pad7[31];              // the redo's size, decided ONCE: 0 = not yet, TEAM_GO_LONE = every stayer by
-                                                        // itself, else n = the final `seen` (stored by the last finisher)
+                                                        // itself, else n = the number of stayers (stored by the last finisher)
     unsigned redo_done; unsigned pad8[31];              // workgroups of the redo that have finished it (team_redo_done)
-    unsigned gen;       unsigned pad9[31];              // != 0: the launch (Problem::launch_seq) whose workgroup 0 wrote this block
-                                                        // after a redo WITHOUT counters; that launch's own late workgroups must
-                                                        // not take the block for a clean one (team_form)
 };
+static_assert(offsetof(TeamCtl, fallbacks) == 1664, "functional.workspace_fallback_count reads byte 1664");
+static_assert(offsetof(TeamCtl, gen) == offsetof(TeamCtl, magic) + 4 && offsetof(TeamCtl, magic) % 16 == 0, "magic | gen: one 8-byte word");
 constexpr unsigned TEAM_GO_LONE = 0xFFFFFFFFu;
 constexpr unsigned long long TEAM_FINISH_TICKS = 5000000ull;    // 50 ms: the whole grid has finished (every inner wait is bounded
                                                                 // by 4 ms and gives up as soon as the abort word rises)
@@ -70,17 +76,12 @@ constexpr size_t team_head_bytes() { return (sizeof(TeamCtl) + 64 * 3 * 128 + 25
 // zero `bytes` at `head` (a multiple of 16) and set the magic (and, for diagnostics, the abort word): one small launch
 hipError_t launch_team_head_init(void* head, size_t bytes, bool raise_abort, hipStream_t stream);
 // a clean block (zeros + magic + the surviving fall-back count) over `n16` 16-byte pieces; called by one wave (64 threads).
-// `gen` != 0 marks the block as written by that launch's redo without counters (TeamCtl::gen).
+// `gen` != 0 marks the block as written by that launch's redo without counters (TeamCtl::gen; it travels in the magic's piece).
 __device__ __forceinline__ void team_head_rewrite(unsigned* head, int n16, unsigned fallbacks, unsigned gen = 0u) {
     constexpr int magic_piece = (int)(offsetof(TeamCtl, magic) / 16), fb_piece = (int)(offsetof(TeamCtl, fallbacks) / 16);
-    constexpr int gen_piece = (int)(offsetof(TeamCtl, gen) / 16);
     uint4* h16 = reinterpret_cast<uint4*>(head);
     for (int i = threadIdx.x & 63; i < n16; i += 64)
-        if (i != magic_piece)
-            h16[i] = make_uint4(i == fb_piece ? fallbacks : (i == gen_piece ? gen : 0u), 0u, 0u, 0u);
-    // the magic goes last, behind the rest of the block: a reader that finds it finds the zeros (and `gen`) too
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) h16[magic_piece] = make_uint4(TEAM_MAGIC, 0u, 0u, 0u);
+        h16[i] = make_uint4(i == magic_piece ? TEAM_MAGIC : (i == fb_piece ? fallbacks : 0u), i == magic_piece ? gen : 0u, 0u, 0u);
 }
 struct TeamFlags {                                      // per team
     unsigned c1;        unsigned pad0[31];              // hand-off 1 (unit centroids published)
@@ -128,8 +129,10 @@ __device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, T
 __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh, unsigned launch_seq = 0u) {
     bool trusted = false;
     if (threadIdx.x == 0) {
-        trusted = ld_poll(&ctl->magic) == TEAM_MAGIC;
-        if (trusted && launch_seq != 0u) trusted = ld_poll(&ctl->gen) != launch_seq;
+        const unsigned long long mg = __hip_atomic_load(
+            reinterpret_cast<const unsigned long long*>(__builtin_assume_aligned(&ctl->magic, 8)), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);      // magic | gen << 32, one load (the control block is 256-byte aligned, magic at 1536)
+        trusted = (unsigned)mg == TEAM_MAGIC && (launch_seq == 0u || (unsigned)(mg >> 32) != launch_seq);
     }
     if (threadIdx.x == 0 && !trusted) {
         // not a clean control block (fresh or overwritten memory): no counter in it can be trusted, so no teams and no
@@ -162,7 +165,7 @@ __device__ __forceinline__ TeamId team_form(TeamCtl* ctl, int* sh, unsigned laun
 // End of a team launch on a TRUSTED control block, called by all threads of every workgroup (also the ones without a team or
 // without a batch).  The common case costs one load and one atomic and waits for nobody: a workgroup that finds the abort
 // word down counts itself in `done` and leaves; the one that completes the count rewrites the block (everybody else has
-// left).  A workgroup that finds the abort word UP takes a rank in `seen`, counts itself in `done` as well and STAYS until
+// left).  A workgroup that finds the abort word UP takes a rank and counts itself in `done` (one atomic) and STAYS until
 // the last finisher has published how many of them there are (`go`).  Those that stayed
 // redo the call with the one-workgroup-per-batch body, batches rank, rank + n, ...: all of the grid when no team could
 // form (the word is up before anybody finishes), at least the team whose hand-off ran out otherwise.  Returns the number of
@@ -174,14 +177,14 @@ __device__ __forceinline__ unsigned cas_agent(unsigned* p, unsigned expected, un
     return expected;
 }
 // The size of the redo is decided ONCE, by the last finisher, and published in `go` (round 6; until then every stayer read
-// `seen` for itself once `done` was complete -- but a last finisher that found the word risen late bumped `seen` AFTER
-// that, and nothing ordered a stayer's two relaxed adds: stayers could leave with different n, and strides rank, rank + n,
-// ... over different n do not tile the batches):
-//   * a workgroup that stays takes its rank in `seen`, WAITS for that add (s_waitcnt vmcnt(0), as team_form does between its
-//     two adds) and only then counts itself in `done`;
-//   * the workgroup whose `done` add completes the grid therefore reads the final `seen`.  It stores it in `go` -- or, with
-//     nobody staying, rewrites the block.  If it finds the abort word risen only now it does NOT join: whoever raised the
-//     word stays, and the stayers cover every batch;
+// a counter `seen` for itself once `done` was complete -- but a last finisher that found the word risen late bumped `seen`
+// AFTER that, and nothing ordered a stayer's two relaxed adds: stayers could leave with different n, and strides rank,
+// rank + n, ... over different n do not tile the batches):
+//   * `done` carries both counts: a workgroup that stays adds 0x10001 (its rank = the old high half), one that leaves adds 1.
+//     One atomic per workgroup: there is no second add to order;
+//   * the workgroup whose add completes the low half therefore holds the final number of stayers.  It stores it in `go` -- or,
+//     with nobody staying, rewrites the block.  If it finds the abort word risen only now it does NOT join: whoever raised
+//     the word stays, and the stayers cover every batch;
 //   * stayers spin on `go`.  A stayer whose wait runs out (50 ms: a workgroup of this grid has not finished) moves `go` from
 //     0 to TEAM_GO_LONE -- a compare-and-swap, so that either EVERY stayer redoes the call alone in the slice of its own block
 //     index, or every stayer takes part in the ranked redo; the two never mix (they would share workspace slices).
@@ -192,16 +195,13 @@ __device__ __forceinline__ TeamRedo team_finish(TeamCtl* ctl, int* sh, int n16, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this workgroup's results are out
         int n = 0, rank = 0, clean = 0;
         const unsigned up = ld_poll(&ctl->abort_) | (known_up ? 1u : 0u);
-        if (up) {
-            rank = (int)add_agent(&ctl->seen, 1u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the rank is taken before `done` moves
-        }
-        const bool last = add_agent(&ctl->done, 1u) == gridDim.x - 1;
+        const unsigned v = add_agent(&ctl->done, up ? 0x10001u : 1u);   // (grid <= 65 535 workgroups: one per CU)
+        rank = (int)(v >> 16);
+        const bool last = (v & 0xFFFFu) == gridDim.x - 1;
         unsigned g = 0u;
         if (last) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned s = ld_poll(&ctl->seen);                 // final: every other workgroup has left or holds its rank
-            if (s == 0u) clean = 1;                                 // nobody stays (up implies s >= 1)
+            const unsigned s = (v >> 16) + (up ? 1u : 0u);          // final: every other workgroup has left or holds its rank
+            if (s == 0u) clean = 1;                                 // nobody stays
             else {
                 g = cas_agent(&ctl->go, 0u, s);                     // 0 -> n; a stayer may have declared TEAM_GO_LONE meanwhile
                 if (g == 0u) g = s;
