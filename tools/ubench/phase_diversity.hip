@@ -1,0 +1,114 @@
+// Would TWO unsynchronised 4-wave workgroups per CU overlap the CU's pipes better than ONE barrier-locked 8-wave workgroup?
+// (tools only.)  The forward-only team kernel runs at the SUM of its pipes: all eight waves of its one
+// workgroup per CU are in the same phase, so vector issue (A1, A2, S), the matrix pipe + LDS fragment reads (X) and the LDS
+// reads of S take turns.  A sixteen-member team with 40 rows per member would fit two workgroups per CU (65 KB of LDS each)
+// whose phases are not tied together.  Before rebuilding the kernel for that, this loop runs the kernel's per-wave
+// instruction mix -- phase A1: 123 vector instructions; X: 60 MFMA 16x16x32 with 45 ds_read_b128 and 54 vector instructions;
+// barrier; A2: 257 vector instructions + 20 ds_write_b64; S: 16 ds_read_b128 + 278 vector instructions of which 22
+// transcendental; barrier -- as (a) 256 workgroups x 8 waves and (b) 512 workgroups x 4 waves (two per CU), same work per wave.
+//   hipcc -O3 --offload-arch=gfx950 -o phase_diversity phase_diversity.hip && ./phase_diversity
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ __forceinline__ void valu(float (&x)[8], float a) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i & 7]) : "v"(a));
+}
+template <int N>
+__device__ __forceinline__ void trans(float (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i & 7]));
+}
+
+// WAVES = waves per workgroup; LDS per workgroup = WAVES x 16 KB
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_phases(float* sink, int iters, float a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < WAVES * 4096; i += 64 * WAVES) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
+    __syncthreads();
+    const unsigned base = (unsigned)(size_t)smem + wid * 16384 + lane * 16;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+    h8 fa, fb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = (_Float16)(0.01f * (lane + i)); fb[i] = (_Float16)(0.02f * (lane - i)); }
+    f32x4 acc[4] = {};
+    for (int it = 0; it < iters; ++it) {
+        valu<123>(x, a);                                                   // A1
+        // X: 60 MFMA, 45 ds_read_b128, 54 VALU (fragment reads one K-step ahead)
+#pragma unroll
+        for (int s = 0; s < 15; ++s) {
+            f32x4 v[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[r]) : "v"(base + (unsigned)((s & 3) * 1024)), "n"(0));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[m], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            x[0] += v[0][0] + v[1][1] + v[2][2];
+            valu<1>(x, a);
+        }
+        __syncthreads();
+        valu<257>(x, a);                                                   // A2
+#pragma unroll
+        for (int r = 0; r < 20; ++r)
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(base + (unsigned)(r * 512 % 8192)), "v"(*reinterpret_cast<double*>(&x[r & 6])), "n"(0) : "memory");
+        {                                                                  // S
+            f32x4 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[r]) : "v"(base + (unsigned)(r * 1024 % 16384 - (r * 1024 % 16384 >= 15360 ? 1024 : 0))), "n"(0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r & 7] += v[r][r & 3];
+            valu<240>(x, a);
+            trans<22>(x);
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) s += acc[m][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    int cus = 0;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    float* sink;
+    CK(hipMalloc(&sink, 256));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time = [&](auto launch) {
+        launch(100);
+        CK(hipEventRecord(e0));
+        launch(iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3 / iters;
+    };
+    int nb4 = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_phases<4>, 256, 4 * 16384));
+    for (int rep = 0; rep < 3; ++rep) {
+        const double a8 = time([&](int n) { hipLaunchKernelGGL(k_phases<8>, dim3(cus), dim3(512), 8 * 16384, 0, sink, n, 1.0001f); });
+        const double b4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(2 * cus), dim3(256), 4 * 16384, 0, sink, n, 1.0001f); });
+        const double c4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(cus), dim3(256), 4 * 16384, 0, sink, n, 1.0001f); });
+        printf("per iteration: one 8-wave workgroup per CU %.3f us | two 4-wave workgroups per CU (occupancy %d) %.3f us | one 4-wave workgroup per CU (half the work) %.3f us"
+               "  ->  two independent workgroups take %.2f of the barrier-locked one's time\n", a8, nb4, b4, c4, b4 / a8);
+    }
+    return 0;
+}
