@@ -25,14 +25,14 @@ __device__ __forceinline__ void trans(float (&x)[8]) {
     for (int i = 0; i < N; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i & 7]));
 }
 
-// WAVES = waves per workgroup; LDS per workgroup = WAVES x 16 KB
+// WAVES = waves per workgroup; LDS per workgroup = WAVES x 8 KB
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_phases(float* sink, int iters, float a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < WAVES * 4096; i += 64 * WAVES) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
+    for (int i = threadIdx.x; i < WAVES * 2048; i += 64 * WAVES) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
     __syncthreads();
-    const unsigned base = (unsigned)(size_t)smem + wid * 16384 + lane * 16;
+    const unsigned base = (unsigned)(size_t)smem + wid * 8192 + lane * 16;
     float x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_phases(float* sink, int iters, f
         valu<257>(x, a);                                                   // A2
 #pragma unroll
         for (int r = 0; r < 20; ++r)
-            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(base + (unsigned)(r * 512 % 8192)), "v"(*reinterpret_cast<double*>(&x[r & 6])), "n"(0) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(base + (unsigned)(r * 512 % 4096)), "v"(*reinterpret_cast<double*>(&x[r & 6])), "n"(0) : "memory");
         {                                                                  // S
             f32x4 v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[r]) : "v"(base + (unsigned)(r * 1024 % 16384 - (r * 1024 % 16384 >= 15360 ? 1024 : 0))), "n"(0));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[r]) : "v"(base + (unsigned)(r * 1024 % 7168)), "n"(0));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r & 7] += v[r][r & 3];
@@ -87,8 +87,9 @@ int main(int argc, char** argv) {
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     float* sink;
     CK(hipMalloc(&sink, 256));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phases<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto time = [&](auto launch) {
@@ -102,13 +103,14 @@ int main(int argc, char** argv) {
         return ms * 1e3 / iters;
     };
     int nb4 = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_phases<4>, 256, 4 * 16384));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, k_phases<4>, 256, 4 * 8192));
     for (int rep = 0; rep < 3; ++rep) {
-        const double a8 = time([&](int n) { hipLaunchKernelGGL(k_phases<8>, dim3(cus), dim3(512), 8 * 16384, 0, sink, n, 1.0001f); });
-        const double b4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(2 * cus), dim3(256), 4 * 16384, 0, sink, n, 1.0001f); });
-        const double c4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(cus), dim3(256), 4 * 16384, 0, sink, n, 1.0001f); });
+        const double a8 = time([&](int n) { hipLaunchKernelGGL(k_phases<8>, dim3(cus), dim3(512), 8 * 8192, 0, sink, n, 1.0001f); });
+        const double b4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(2 * cus), dim3(256), 4 * 8192, 0, sink, n, 1.0001f); });
+        const double c4 = time([&](int n) { hipLaunchKernelGGL(k_phases<4>, dim3(cus), dim3(256), 4 * 8192, 0, sink, n, 1.0001f); });
+        const double d16 = time([&](int n) { hipLaunchKernelGGL(k_phases<16>, dim3(cus), dim3(1024), 16 * 8192, 0, sink, n, 1.0001f); });
         printf("per iteration: one 8-wave workgroup per CU %.3f us | two 4-wave workgroups per CU (occupancy %d) %.3f us | one 4-wave workgroup per CU (half the work) %.3f us"
-               "  ->  two independent workgroups take %.2f of the barrier-locked one's time\n", a8, nb4, b4, c4, b4 / a8);
+               "  ->  two independent workgroups take %.2f of the barrier-locked one's time | one 16-wave workgroup per CU (twice the work) %.3f us = %.2f x the 8-wave throughput\n", a8, nb4, b4, c4, b4 / a8, d16, 2.0 * a8 / d16);
     }
     return 0;
 }
